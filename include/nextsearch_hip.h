@@ -1,0 +1,137 @@
+/*
+ * nextsearch_hip.h — C-ABI of libnextsearch_hip.so: the MI355X (gfx950) posting-traversal /
+ * BM25-scoring / top-k hot path of NextSearch's cord19::Engine::search.
+ *
+ * The reference has no FFI seam: the path is an inline loop inside Engine::search.  The boundary is
+ * therefore cut where that loop begins and ends (reference file:line, /root/reference/...):
+ *
+ *   enter : src/api_engine.cpp:441   (qterms_w final; per segment: lexicon probe :454-458 and
+ *                                     bm25_idf :45-47,:461 stay on the HOST and arrive here as
+ *                                     ns_term_ref{byte_off,count,idf,qweight})
+ *   leave : src/api_engine.cpp:504-505 (hits sorted by score + total_found)
+ *
+ * Everything is plain-old-data; no exceptions cross the boundary; every entry point returns
+ * NS_OK (0) or a negative NS_E* code and leaves a message retrievable with ns_last_error().
+ * There is NO CPU fallback: without a usable HIP device ns_ctx_create fails with NS_E_NODEVICE.
+ *
+ * Threading: an ns_ctx is bound to one device and one stream and is not re-entrant (the reference
+ * serialises every engine entry behind Engine::mtx, src/api_engine.cpp:372).  Segments are
+ * immutable after upload.  Use one ctx per host thread / per GPU.
+ */
+#ifndef NEXTSEARCH_HIP_H
+#define NEXTSEARCH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NS_OK            0
+#define NS_E_INVAL      -1   /* bad argument (null pointer, K out of range, offset outside segment ...) */
+#define NS_E_NODEVICE   -2   /* no HIP device / HIP runtime failure at init */
+#define NS_E_HIP        -3   /* a HIP call failed; see ns_last_error */
+#define NS_E_NOMEM      -4
+#define NS_E_STATE      -5   /* call sequence error (e.g. fetch before run) */
+
+#define NS_MAX_K        100u /* src/api_engine.cpp:377: K = clamp(k,1,100) */
+
+/* flags for ns_search_batch / ns_batch_prepare */
+#define NS_FLAG_OR      0u   /* reference semantics: every touched doc is a candidate (src/api_engine.cpp:449-492) */
+#define NS_FLAG_AND     1u   /* extension (BASELINE config 2): keep docs matched by every term ref of their segment */
+
+typedef struct ns_ctx   ns_ctx;
+typedef struct ns_seg   ns_seg;
+typedef struct ns_batch ns_batch;
+
+/* One scored (query term, segment) pair — replaces the reference's
+ * {seg.lex.find(term) -> LexEntry; bm25_idf(seg.N,e.df); seekg(e.offset)} triple
+ * (src/api_engine.cpp:454-470).  Refs of one query are contiguous and in QUERY-TERM ORDER; refs of
+ * different segments may interleave (their relative order per segment is what matters: it is the
+ * fp32 accumulation order of src/api_engine.cpp:480). */
+typedef struct ns_term_ref {
+    uint32_t seg_id;     /* id given to ns_segment_upload */
+    uint32_t count;      /* LexEntry.count: postings in the list (include/api_types.hpp:27) */
+    uint64_t byte_off;   /* byte offset of the list inside the uploaded posting buffer (multiple of 8) */
+    float    idf;        /* host-computed bm25_idf(N, df) (src/api_engine.cpp:45-47) */
+    float    qweight;    /* 1.0f, or the semantic-expansion weight (src/api_engine.cpp:410-421) */
+} ns_term_ref;
+
+typedef struct ns_query_desc {
+    uint32_t term_begin; /* first ns_term_ref of this query */
+    uint32_t term_count; /* may be 0: such a query returns nhits = 0, found = 0 */
+} ns_query_desc;
+
+/* struct Hit {float s; uint32_t segId; uint32_t docId;} (src/api_engine.cpp:427-431) */
+typedef struct ns_hit {
+    float    score;
+    uint32_t seg_id;
+    uint32_t doc_id;
+} ns_hit;
+
+typedef struct ns_batch_info {
+    uint64_t postings;        /* P = sum over term refs of count */
+    uint64_t algo_bytes;      /* 8 * P: algorithmic bytes of one run */
+    uint32_t n_queries;
+    uint32_t n_items;         /* (query, segment, doc-range) work items == workgroups of the scoring kernel */
+    uint32_t n_term_refs;
+    uint32_t tile_docs;       /* docs per LDS accumulator tile */
+    uint32_t k;
+    uint32_t flags;
+    float    last_score_kernel_ms; /* HIP-event time of the scoring kernel in the last timed run, <0 if none */
+    float    last_total_ms;        /* HIP-event time of all kernels of the last timed run, <0 if none */
+} ns_batch_info;
+
+/* ---- context ------------------------------------------------------------------------------ */
+int  ns_ctx_create(int device, ns_ctx** out);
+void ns_ctx_destroy(ns_ctx* ctx);
+/* Use an externally owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) for all work
+ * of this ctx; NULL restores the ctx's own stream. */
+int  ns_ctx_set_stream(ns_ctx* ctx, void* hip_stream);
+/* Message of the last failing call on this ctx (ctx == NULL: last failing ns_ctx_create of the
+ * calling thread).  Never NULL. */
+const char* ns_last_error(ns_ctx* ctx);
+/* "gfx950 ..." device string of the ctx's device */
+const char* ns_device_name(ns_ctx* ctx);
+
+/* ---- segments (replaces the reference's open ifstreams: include/api_types.hpp:54-59) ------- */
+/* Copies doc_len[N] and the flattened posting payload (all inverted_bNNN.bin back to back, or
+ * inverted.bin) to HBM through a pinned staging buffer, once; precomputes the per-doc BM25 norm
+ * k1*((1-b) + b*(dl/avgdl)) in fp32 with the reference's operation order (src/api_engine.cpp:478).
+ * Host buffers stay owned by the caller and may be freed on return. */
+int ns_segment_upload(ns_ctx* ctx, uint32_t seg_id, uint32_t n_docs, float avgdl,
+                      const uint32_t* doc_len, const void* postings, uint64_t nbytes, ns_seg** out);
+int ns_segment_release(ns_ctx* ctx, ns_seg* seg);
+
+/* ---- one-shot search (host buffers in, host buffers out) ------------------------------------ */
+/* hits_out: Q*K entries, query-major, best first: score desc, then seg_id asc, then doc_id asc
+ * (the reference leaves ties unspecified: src/api_engine.cpp:485-492); unused tail entries are
+ * {-inf, 0xFFFFFFFF, 0xFFFFFFFF}.  nhits_out[Q], found_out[Q] (src/api_engine.cpp:495,505). */
+int ns_search_batch(ns_ctx* ctx, const ns_query_desc* queries, const ns_term_ref* terms,
+                    uint32_t n_queries, uint32_t k, ns_hit* hits_out, uint32_t* nhits_out,
+                    uint64_t* found_out, uint32_t flags);
+
+/* ---- staged search (descriptors resident in HBM; what bench.py times) ----------------------- */
+int  ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const ns_term_ref* terms,
+                      uint32_t n_queries, uint32_t k, uint32_t flags, ns_batch** out);
+/* Optional: write results into caller-owned DEVICE buffers (e.g. torch tensors that are then
+ * all-gathered by RCCL): d_hits Q*K ns_hit, d_nhits Q u32, d_found Q u64.  NULLs restore the
+ * batch's own buffers. */
+int  ns_batch_bind_outputs(ns_batch* b, void* d_hits, void* d_nhits, void* d_found);
+/* Enqueue one pass of the hot path on the ctx stream (asynchronous).  timed != 0 brackets the
+ * kernels with HIP events on that stream (read back through ns_batch_get_info after a sync). */
+int  ns_batch_run(ns_batch* b, int timed);
+int  ns_batch_sync(ns_batch* b);
+int  ns_batch_fetch(ns_batch* b, ns_hit* hits_out, uint32_t* nhits_out, uint64_t* found_out);
+int  ns_batch_get_info(ns_batch* b, ns_batch_info* info);
+void ns_batch_destroy(ns_batch* b);
+
+/* ---- tuning knobs (process-wide defaults; 0 = library default) ------------------------------ */
+/* variant: 0 = default, see DESIGN.md "kernel variants".  min_items: target number of work items
+ * below which queries are split across doc ranges. */
+int  ns_set_tuning(ns_ctx* ctx, uint32_t variant, uint32_t min_items);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEXTSEARCH_HIP_H */

@@ -1,0 +1,67 @@
+/*
+ * nextsearch_host.h — C wrappers over the C++ host facade (nextsearch::Engine, the mirror of the
+ * reference's cord19::Engine, include/api_engine.hpp:23-91) so that Python tests and bench.py can
+ * drive it through ctypes.  The compute entry points all go through include/nextsearch_hip.h; this
+ * header adds no scoring code and no CPU fallback.
+ */
+#ifndef NEXTSEARCH_HOST_H
+#define NEXTSEARCH_HOST_H
+
+#include <stdint.h>
+
+#include "nextsearch_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nsh_engine nsh_engine;
+
+/* Deterministic synthetic index in the reference's on-disk format. */
+int nsh_gen_index(const char* index_dir, uint32_t n_segments, uint32_t docs_per_segment, uint32_t vocab,
+                  uint64_t seed, int legacy_layout, uint64_t* total_postings_out);
+
+/* Engine::reload() on index_dir.  device >= 0: create an ns_ctx on that GPU and upload every
+ * segment; device < 0: host-only (index + query preparation; search calls fail).  On failure
+ * returns non-zero and *out still receives an engine whose nsh_engine_error() explains why
+ * (free it with nsh_engine_close). */
+int  nsh_engine_open(const char* index_dir, int device, nsh_engine** out);
+void nsh_engine_close(nsh_engine* e);
+const char* nsh_engine_error(nsh_engine* e);
+ns_ctx* nsh_engine_ctx(nsh_engine* e);
+
+uint32_t nsh_engine_num_segments(nsh_engine* e);
+const char* nsh_engine_segment_name(nsh_engine* e, uint32_t seg);
+int nsh_engine_segment_info(nsh_engine* e, uint32_t seg, uint32_t* n_docs, float* avgdl, uint64_t* n_postings,
+                            uint32_t* n_terms, int* use_barrels);
+/* Host copies of what gets uploaded (valid until close/reload). */
+const uint32_t* nsh_engine_segment_doc_len(nsh_engine* e, uint32_t seg);
+const void* nsh_engine_segment_postings(nsh_engine* e, uint32_t seg, uint64_t* nbytes);
+/* Lexicon probe (src/api_engine.cpp:454-461).  Returns 1 if found, 0 if absent. */
+int nsh_engine_lookup(nsh_engine* e, uint32_t seg, const char* term, uint32_t* term_id, uint32_t* df, uint32_t* count,
+                      uint64_t* byte_off, float* idf);
+
+float nsh_bm25_idf(uint32_t n_docs, uint32_t df);
+/* Tokenise + filter (include/textutil.hpp:13-37, src/api_engine.cpp:391-397): writes the kept terms
+ * separated by single spaces into buf (NUL-terminated, truncated to cap); returns the term count. */
+uint32_t nsh_base_terms(const char* query, char* buf, uint32_t cap);
+
+/* Query preparation only: fills qd[n_queries], usable[n_queries] and up to refs_cap refs;
+ * *n_refs receives the number needed.  Returns 0, or 1 if refs_cap was too small. */
+int nsh_engine_build_refs(nsh_engine* e, const char* const* queries, uint32_t n_queries, ns_query_desc* qd,
+                          ns_term_ref* refs, uint32_t refs_cap, uint32_t* n_refs, uint8_t* usable);
+
+/* Engine::search(query, k) -> JSON text with the reference's keys; caller frees with nsh_free. */
+int  nsh_engine_search_json(nsh_engine* e, const char* query, int k, char** json_out);
+void nsh_free(void* p);
+/* Batch search through ns_search_batch.  hits: n_queries*K (K = clamp(k,1,100)). */
+int nsh_engine_search_batch(nsh_engine* e, const char* const* queries, uint32_t n_queries, int k, uint32_t flags,
+                            ns_hit* hits, uint32_t* nhits, uint64_t* found, uint8_t* has_found);
+/* Staged: query prep on the host, descriptors to the device; drive the result with ns_batch_*. */
+int nsh_engine_prepare(nsh_engine* e, const char* const* queries, uint32_t n_queries, int k, uint32_t flags,
+                       ns_batch** out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEXTSEARCH_HOST_H */

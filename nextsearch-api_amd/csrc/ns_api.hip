@@ -1,0 +1,537 @@
+// C-ABI implementation of include/nextsearch_hip.h: context, segment upload (pinned staging),
+// batch preparation (term groups -> work items), kernel launches and result fetch.
+// No CPU fallback exists in this library: every compute entry point needs a live HIP device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/nextsearch_hip.h"
+#include "ns_internal.h"
+#include "ns_kernels.hip"
+
+using namespace ns;
+
+static_assert(sizeof(ns_hit) == sizeof(Hit), "ns_hit layout");
+
+// ------------------------------------------------------------------------------------------------
+struct ns_seg {
+    ns_ctx* ctx = nullptr;
+    uint32_t id = 0;
+    uint32_t n_docs = 0;
+    uint64_t n_postings = 0;
+    uint2* d_postings = nullptr;
+    float* d_norm = nullptr;
+};
+
+struct ns_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::string devname;
+    int n_cus = 0;
+    std::vector<ns_seg*> segs;   // indexed by seg_id
+    uint32_t variant = 0;
+    uint32_t min_items = 0;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(ns_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_err = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail((ctx), NS_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// Kernel variants (DESIGN.md "kernel variants"): threads per workgroup, slots per thread, postings
+// per thread per round.  tile_docs = NT * SPT.
+struct VariantDesc { uint32_t nt, spt, u; };
+static const VariantDesc kVariants[] = {
+    {512, 12, 4},    // 0: default (same as 2)
+    {1024, 12, 4},   // 1: 12288-doc tiles, 2 workgroups/CU
+    {512, 12, 4},    // 2:  6144-doc tiles, 4 workgroups/CU
+    {256, 16, 4},    // 3:  4096-doc tiles, 7 workgroups/CU
+    {512, 16, 8},    // 4:  8192-doc tiles, 3 workgroups/CU
+};
+static constexpr uint32_t kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+
+template <int NT, int SPT, int U>
+static void launch_score(bool and_mode, uint32_t n_items, hipStream_t st, const DevItem* items, const DevTerm* terms,
+                         const DevSeg* segs, const uint32_t* bounds, Hit* hits, uint32_t* nhits, uint64_t* found,
+                         uint32_t K) {
+    if (and_mode)
+        hipLaunchKernelGGL((k_score<NT, SPT, U, true>), dim3(n_items), dim3(NT), 0, st, items, terms, segs, bounds, hits, nhits, found, K);
+    else
+        hipLaunchKernelGGL((k_score<NT, SPT, U, false>), dim3(n_items), dim3(NT), 0, st, items, terms, segs, bounds, hits, nhits, found, K);
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int ns_ctx_create(int device, ns_ctx** out) {
+    if (!out) return fail(nullptr, NS_E_INVAL, "ns_ctx_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, NS_E_NODEVICE, "no HIP device available (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(nullptr, NS_E_INVAL, "device %d out of range [0,%d)", device, ndev);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(nullptr, NS_E_NODEVICE, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return fail(nullptr, NS_E_NODEVICE, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    ns_ctx* ctx = new ns_ctx();
+    ctx->device = device;
+    ctx->devname = std::string(prop.gcnArchName) + " " + prop.name;
+    ctx->n_cus = prop.multiProcessorCount;
+    e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        int rc = fail(nullptr, NS_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+        delete ctx;
+        return rc;
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return NS_OK;
+}
+
+extern "C" void ns_ctx_destroy(ns_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (ns_seg* s : ctx->segs) {
+        if (!s) continue;
+        (void)hipFree(s->d_postings);
+        (void)hipFree(s->d_norm);
+        delete s;
+    }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+extern "C" int ns_ctx_set_stream(ns_ctx* ctx, void* hip_stream) {
+    if (!ctx) return fail(nullptr, NS_E_INVAL, "ns_ctx_set_stream: ctx is NULL");
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return NS_OK;
+}
+
+extern "C" const char* ns_last_error(ns_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+extern "C" const char* ns_device_name(ns_ctx* ctx) { return ctx ? ctx->devname.c_str() : ""; }
+
+extern "C" int ns_set_tuning(ns_ctx* ctx, uint32_t variant, uint32_t min_items) {
+    if (!ctx) return fail(nullptr, NS_E_INVAL, "ns_set_tuning: ctx is NULL");
+    if (variant >= kNumVariants) return fail(ctx, NS_E_INVAL, "unknown kernel variant %u", variant);
+    ctx->variant = variant;
+    ctx->min_items = min_items;
+    return NS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int ns_segment_upload(ns_ctx* ctx, uint32_t seg_id, uint32_t n_docs, float avgdl, const uint32_t* doc_len,
+                                 const void* postings, uint64_t nbytes, ns_seg** out) {
+    if (!ctx) return fail(nullptr, NS_E_INVAL, "ns_segment_upload: ctx is NULL");
+    if (out) *out = nullptr;
+    if (seg_id >= (1u << 20)) return fail(ctx, NS_E_INVAL, "seg_id %u too large", seg_id);
+    if (nbytes % 8 != 0) return fail(ctx, NS_E_INVAL, "posting payload of %llu bytes is not a whole number of {u32,u32} pairs", (unsigned long long)nbytes);
+    if ((n_docs && !doc_len) || (nbytes && !postings)) return fail(ctx, NS_E_INVAL, "null doc_len/postings");
+    if (seg_id < ctx->segs.size() && ctx->segs[seg_id]) return fail(ctx, NS_E_INVAL, "segment %u already uploaded", seg_id);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+
+    ns_seg* s = new ns_seg();
+    s->ctx = ctx;
+    s->id = seg_id;
+    s->n_docs = n_docs;
+    s->n_postings = nbytes / 8;
+    auto cleanup = [&]() { (void)hipFree(s->d_postings); (void)hipFree(s->d_norm); delete s; };
+
+    hipError_t e;
+    uint32_t* d_len = nullptr;
+    // +16 B slack so vector loads at the tail stay inside the allocation
+    if ((e = hipMalloc((void**)&s->d_postings, nbytes + 16)) != hipSuccess) { cleanup(); return fail(ctx, NS_E_NOMEM, "hipMalloc postings (%llu B): %s", (unsigned long long)nbytes, hipGetErrorString(e)); }
+    if ((e = hipMalloc((void**)&s->d_norm, (size_t)std::max<uint32_t>(n_docs, 1) * 4)) != hipSuccess) { cleanup(); return fail(ctx, NS_E_NOMEM, "hipMalloc norm: %s", hipGetErrorString(e)); }
+    if ((e = hipMalloc((void**)&d_len, (size_t)std::max<uint32_t>(n_docs, 1) * 4)) != hipSuccess) { cleanup(); return fail(ctx, NS_E_NOMEM, "hipMalloc doc_len: %s", hipGetErrorString(e)); }
+
+    // pinned, double-buffered staging: host memcpy of chunk i+1 overlaps the DMA of chunk i
+    const size_t kChunk = 32u << 20;
+    void* pin[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool ok = true;
+    for (int i = 0; i < 2 && ok; i++) {
+        ok = hipHostMalloc(&pin[i], kChunk, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
+    }
+    auto stage = [&](void* dst, const void* src, size_t n) -> hipError_t {
+        size_t off = 0;
+        int k = 0;
+        while (off < n) {
+            size_t c = std::min(kChunk, n - off);
+            hipError_t r = hipEventSynchronize(ev[k]);
+            if (r != hipSuccess) return r;
+            std::memcpy(pin[k], (const char*)src + off, c);
+            r = hipMemcpyAsync((char*)dst + off, pin[k], c, hipMemcpyHostToDevice, ctx->stream);
+            if (r != hipSuccess) return r;
+            r = hipEventRecord(ev[k], ctx->stream);
+            if (r != hipSuccess) return r;
+            off += c;
+            k ^= 1;
+        }
+        return hipSuccess;
+    };
+    e = hipSuccess;
+    if (ok) {
+        if (nbytes) e = stage(s->d_postings, postings, nbytes);
+        if (e == hipSuccess && n_docs) e = stage(d_len, doc_len, (size_t)n_docs * 4);
+        if (e == hipSuccess && n_docs) {
+            hipLaunchKernelGGL(k_norm, dim3((n_docs + 255) / 256), dim3(256), 0, ctx->stream, d_len, s->d_norm, n_docs, avgdl);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+    for (int i = 0; i < 2; i++) {
+        if (pin[i]) (void)hipHostFree(pin[i]);
+        if (ev[i]) (void)hipEventDestroy(ev[i]);
+    }
+    (void)hipFree(d_len);
+    if (!ok) { cleanup(); return fail(ctx, NS_E_NOMEM, "pinned staging allocation failed"); }
+    if (e != hipSuccess) { cleanup(); return fail(ctx, NS_E_HIP, "segment upload: %s", hipGetErrorString(e)); }
+
+    if (ctx->segs.size() <= seg_id) ctx->segs.resize(seg_id + 1, nullptr);
+    ctx->segs[seg_id] = s;
+    if (out) *out = s;
+    return NS_OK;
+}
+
+extern "C" int ns_segment_release(ns_ctx* ctx, ns_seg* seg) {
+    if (!ctx || !seg) return fail(ctx, NS_E_INVAL, "ns_segment_release: null argument");
+    if (seg->id >= ctx->segs.size() || ctx->segs[seg->id] != seg) return fail(ctx, NS_E_INVAL, "segment does not belong to this ctx");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(seg->d_postings);
+    (void)hipFree(seg->d_norm);
+    ctx->segs[seg->id] = nullptr;
+    delete seg;
+    return NS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct ns_batch {
+    ns_ctx* ctx = nullptr;
+    uint32_t Q = 0, K = 0, flags = 0;
+    uint32_t variant = 0, tile_docs = 0;
+    uint32_t n_items = 0, n_groups = 0, n_terms = 0, n_parts = 0;
+    uint64_t postings = 0;
+    bool direct = false;   // every query has exactly one work item: k_score writes final rows
+    // device
+    DevItem* d_items = nullptr;
+    DevTerm* d_terms = nullptr;
+    DevGroup* d_groups = nullptr;
+    DevQuery* d_queries = nullptr;
+    DevSeg* d_segs = nullptr;
+    uint32_t* d_bounds = nullptr;
+    Hit* d_part_hits = nullptr;
+    uint32_t* d_part_nhits = nullptr;
+    uint64_t* d_part_found = nullptr;
+    uint32_t* d_heads = nullptr;
+    Hit* d_hits = nullptr;
+    uint32_t* d_nhits = nullptr;
+    uint64_t* d_found = nullptr;
+    // active output pointers (own or bound)
+    Hit* o_hits = nullptr;
+    uint32_t* o_nhits = nullptr;
+    uint64_t* o_found = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ran = false, timed = false;
+    float last_score_ms = -1.0f, last_total_ms = -1.0f;
+};
+
+extern "C" void ns_batch_destroy(ns_batch* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    (void)hipFree(b->d_items); (void)hipFree(b->d_terms); (void)hipFree(b->d_groups); (void)hipFree(b->d_queries);
+    (void)hipFree(b->d_segs); (void)hipFree(b->d_bounds); (void)hipFree(b->d_part_hits); (void)hipFree(b->d_part_nhits);
+    (void)hipFree(b->d_part_found); (void)hipFree(b->d_heads); (void)hipFree(b->d_hits); (void)hipFree(b->d_nhits);
+    (void)hipFree(b->d_found);
+    for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
+    delete b;
+}
+
+template <class T>
+static hipError_t dev_upload(T** dptr, const std::vector<T>& v) {
+    size_t n = std::max<size_t>(v.size(), 1) * sizeof(T);
+    hipError_t e = hipMalloc((void**)dptr, n);
+    if (e != hipSuccess) return e;
+    if (!v.empty()) e = hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    return e;
+}
+
+extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const ns_term_ref* terms, uint32_t n_queries,
+                                uint32_t k, uint32_t flags, ns_batch** out) {
+    if (!ctx) return fail(nullptr, NS_E_INVAL, "ns_batch_prepare: ctx is NULL");
+    if (!out) return fail(ctx, NS_E_INVAL, "ns_batch_prepare: out is NULL");
+    *out = nullptr;
+    if (k < 1 || k > NS_MAX_K) return fail(ctx, NS_E_INVAL, "k=%u outside [1,%u]", k, NS_MAX_K);
+    if (n_queries && !queries) return fail(ctx, NS_E_INVAL, "queries is NULL");
+    if (flags & ~NS_FLAG_AND) return fail(ctx, NS_E_INVAL, "unknown flags 0x%x", flags);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+
+    const VariantDesc vd = kVariants[ctx->variant];
+    const uint32_t tile_docs = vd.nt * vd.spt;
+
+    // per-batch segment table (n_tiles depends on the kernel variant)
+    std::vector<DevSeg> segs(ctx->segs.size());
+    for (size_t i = 0; i < ctx->segs.size(); i++) {
+        DevSeg d{};
+        if (ns_seg* s = ctx->segs[i]) {
+            d.postings = s->d_postings;
+            d.norm = s->d_norm;
+            d.n_postings = s->n_postings;
+            d.n_docs = s->n_docs;
+            d.n_tiles = (s->n_docs + tile_docs - 1) / tile_docs;
+        }
+        segs[i] = d;
+    }
+
+    // ---- regroup term refs by (query, segment), keeping query-term order inside each group ----
+    std::vector<DevTerm> dterms;
+    std::vector<DevGroup> groups;
+    std::vector<uint32_t> group_query;
+    std::vector<uint64_t> group_cost;
+    std::vector<uint32_t> qgroup_begin(n_queries + 1, 0);
+    uint64_t bounds_total = 0, postings_total = 0;
+    std::vector<uint32_t> seg_ids;   // scratch
+    for (uint32_t q = 0; q < n_queries; q++) {
+        qgroup_begin[q] = (uint32_t)groups.size();
+        const ns_query_desc qd = queries[q];
+        if (qd.term_count && !terms) return fail(ctx, NS_E_INVAL, "terms is NULL");
+        seg_ids.clear();
+        for (uint32_t i = 0; i < qd.term_count; i++) {
+            const ns_term_ref& r = terms[qd.term_begin + i];
+            if (r.seg_id >= ctx->segs.size() || !ctx->segs[r.seg_id]) return fail(ctx, NS_E_INVAL, "query %u term %u: unknown segment %u", q, i, r.seg_id);
+            const ns_seg* s = ctx->segs[r.seg_id];
+            if (r.byte_off % 8 != 0) return fail(ctx, NS_E_INVAL, "query %u term %u: byte_off %llu not a multiple of 8", q, i, (unsigned long long)r.byte_off);
+            if (r.byte_off / 8 + r.count > s->n_postings) return fail(ctx, NS_E_INVAL, "query %u term %u: list [%llu,+%u) outside segment %u (%llu postings)", q, i, (unsigned long long)(r.byte_off / 8), r.count, r.seg_id, (unsigned long long)s->n_postings);
+            if (std::find(seg_ids.begin(), seg_ids.end(), r.seg_id) == seg_ids.end()) seg_ids.push_back(r.seg_id);
+        }
+        std::sort(seg_ids.begin(), seg_ids.end());   // segments in manifest (id) order, api_engine.cpp:441
+        for (uint32_t sid : seg_ids) {
+            DevGroup g{};
+            g.term_begin = (uint32_t)dterms.size();
+            g.seg = sid;
+            uint64_t cost = 0;
+            for (uint32_t i = 0; i < qd.term_count; i++) {
+                const ns_term_ref& r = terms[qd.term_begin + i];
+                if (r.seg_id != sid) continue;
+                DevTerm t{};
+                t.list_off = r.byte_off / 8;
+                t.count = r.count;
+                t.idf = r.idf;
+                t.weight = r.qweight;
+                t.seg = sid;
+                dterms.push_back(t);
+                cost += r.count;
+            }
+            g.term_count = (uint32_t)dterms.size() - g.term_begin;
+            if ((flags & NS_FLAG_AND) && g.term_count > 255) return fail(ctx, NS_E_INVAL, "AND mode supports at most 255 term refs per (query, segment)");
+            g.bounds_off = bounds_total;
+            bounds_total += (uint64_t)(segs[sid].n_tiles + 1) * g.term_count;
+            postings_total += cost;
+            groups.push_back(g);
+            group_query.push_back(q);
+            group_cost.push_back(cost);
+        }
+    }
+    qgroup_begin[n_queries] = (uint32_t)groups.size();
+    if (bounds_total >= (1ull << 32)) return fail(ctx, NS_E_INVAL, "batch too large: %llu boundary entries; split the batch", (unsigned long long)bounds_total);
+
+    // ---- work items: one per group, or several doc-tile ranges per group for small batches ----
+    const uint32_t min_items = ctx->min_items ? ctx->min_items : (uint32_t)std::max(ctx->n_cus, 1) * 4u;
+    const uint32_t G = (uint32_t)groups.size();
+    uint32_t chunks_per_group = 1;
+    if (G > 0 && G < min_items) chunks_per_group = (min_items + G - 1) / G;
+    std::vector<DevItem> items;
+    std::vector<uint64_t> item_cost;
+    std::vector<DevQuery> dq(n_queries);
+    bool direct = true;
+    for (uint32_t q = 0; q < n_queries; q++) {
+        dq[q].part_begin = (uint32_t)items.size();
+        for (uint32_t gi = qgroup_begin[q]; gi < qgroup_begin[q + 1]; gi++) {
+            const DevGroup& g = groups[gi];
+            uint32_t nt = segs[g.seg].n_tiles;
+            if (nt == 0) continue;   // empty segment: nothing to score
+            uint32_t chunks = std::min(chunks_per_group, nt);
+            uint32_t per = (nt + chunks - 1) / chunks;
+            for (uint32_t tb = 0; tb < nt; tb += per) {
+                DevItem it{};
+                it.bounds_off = g.bounds_off;
+                it.query = q;
+                it.seg = g.seg;
+                it.term_begin = g.term_begin;
+                it.term_count = g.term_count;
+                it.tile_begin = tb;
+                it.tile_end = std::min(nt, tb + per);
+                it.out_slot = (uint32_t)items.size();
+                items.push_back(it);
+                item_cost.push_back(group_cost[gi] * (it.tile_end - it.tile_begin) / nt + 1);
+            }
+        }
+        dq[q].part_count = (uint32_t)items.size() - dq[q].part_begin;
+        if (dq[q].part_count != 1) direct = false;
+    }
+    if (n_queries == 0) direct = false;
+    if (direct) for (auto& it : items) it.out_slot = it.query;
+
+    // longest-processing-time-first launch order (workgroups are dispatched in blockIdx order)
+    std::vector<uint32_t> order(items.size());
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return item_cost[a] > item_cost[b]; });
+    std::vector<DevItem> sorted_items(items.size());
+    for (size_t i = 0; i < order.size(); i++) sorted_items[i] = items[order[i]];
+
+    ns_batch* b = new ns_batch();
+    b->ctx = ctx;
+    b->Q = n_queries; b->K = k; b->flags = flags;
+    b->variant = ctx->variant; b->tile_docs = tile_docs;
+    b->n_items = (uint32_t)items.size(); b->n_groups = G; b->n_terms = (uint32_t)dterms.size();
+    b->n_parts = direct ? 0 : (uint32_t)items.size();
+    b->postings = postings_total;
+    b->direct = direct;
+
+    hipError_t e = hipSuccess;
+    auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    chk(dev_upload(&b->d_items, sorted_items));
+    chk(dev_upload(&b->d_terms, dterms));
+    chk(dev_upload(&b->d_groups, groups));
+    chk(dev_upload(&b->d_queries, dq));
+    chk(dev_upload(&b->d_segs, segs));
+    chk(hipMalloc((void**)&b->d_bounds, std::max<uint64_t>(bounds_total, 1) * 4));
+    const size_t Qn = std::max<uint32_t>(n_queries, 1), Pn = std::max<uint32_t>(b->n_parts, 1);
+    chk(hipMalloc((void**)&b->d_hits, Qn * k * sizeof(Hit)));
+    chk(hipMalloc((void**)&b->d_nhits, Qn * 4));
+    chk(hipMalloc((void**)&b->d_found, Qn * 8));
+    if (!direct) {
+        chk(hipMalloc((void**)&b->d_part_hits, Pn * k * sizeof(Hit)));
+        chk(hipMalloc((void**)&b->d_part_nhits, Pn * 4));
+        chk(hipMalloc((void**)&b->d_part_found, Pn * 8));
+        chk(hipMalloc((void**)&b->d_heads, Pn * 4));
+    }
+    for (auto& ev : b->ev) chk(hipEventCreate(&ev));
+    if (e != hipSuccess) {
+        int rc = fail(ctx, e == hipErrorOutOfMemory ? NS_E_NOMEM : NS_E_HIP, "ns_batch_prepare: %s", hipGetErrorString(e));
+        ns_batch_destroy(b);
+        return rc;
+    }
+    b->o_hits = b->d_hits; b->o_nhits = b->d_nhits; b->o_found = b->d_found;
+    *out = b;
+    return NS_OK;
+}
+
+extern "C" int ns_batch_bind_outputs(ns_batch* b, void* d_hits, void* d_nhits, void* d_found) {
+    if (!b) return NS_E_INVAL;
+    b->o_hits = d_hits ? (Hit*)d_hits : b->d_hits;
+    b->o_nhits = d_nhits ? (uint32_t*)d_nhits : b->d_nhits;
+    b->o_found = d_found ? (uint64_t*)d_found : b->d_found;
+    return NS_OK;
+}
+
+extern "C" int ns_batch_run(ns_batch* b, int timed) {
+    if (!b) return NS_E_INVAL;
+    ns_ctx* ctx = b->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const bool and_mode = (b->flags & NS_FLAG_AND) != 0;
+    if (timed) HIPCHK(ctx, hipEventRecord(b->ev[0], st));
+    if (b->n_groups)
+        hipLaunchKernelGGL(k_bounds, dim3(b->n_groups), dim3(128), 0, st, b->d_groups, b->d_terms, b->d_segs, b->d_bounds, b->tile_docs);
+    if (timed) HIPCHK(ctx, hipEventRecord(b->ev[1], st));
+    Hit* sh = b->direct ? b->o_hits : b->d_part_hits;
+    uint32_t* sn = b->direct ? b->o_nhits : b->d_part_nhits;
+    uint64_t* sf = b->direct ? b->o_found : b->d_part_found;
+    if (b->n_items) {
+        switch (b->variant) {
+            case 1: launch_score<1024, 12, 4>(and_mode, b->n_items, st, b->d_items, b->d_terms, b->d_segs, b->d_bounds, sh, sn, sf, b->K); break;
+            case 3: launch_score<256, 16, 4>(and_mode, b->n_items, st, b->d_items, b->d_terms, b->d_segs, b->d_bounds, sh, sn, sf, b->K); break;
+            case 4: launch_score<512, 16, 8>(and_mode, b->n_items, st, b->d_items, b->d_terms, b->d_segs, b->d_bounds, sh, sn, sf, b->K); break;
+            default: launch_score<512, 12, 4>(and_mode, b->n_items, st, b->d_items, b->d_terms, b->d_segs, b->d_bounds, sh, sn, sf, b->K); break;
+        }
+    }
+    if (timed) HIPCHK(ctx, hipEventRecord(b->ev[2], st));
+    if (!b->direct && b->Q)
+        hipLaunchKernelGGL(k_merge, dim3((b->Q + 3) / 4), dim3(256), 0, st, b->d_queries, b->Q, b->d_part_hits, b->d_part_nhits,
+                           b->d_part_found, b->o_hits, b->o_nhits, b->o_found, b->K, b->d_heads);
+    if (timed) HIPCHK(ctx, hipEventRecord(b->ev[3], st));
+    HIPCHK(ctx, hipGetLastError());
+    b->ran = true;
+    b->timed = timed != 0;
+    return NS_OK;
+}
+
+extern "C" int ns_batch_sync(ns_batch* b) {
+    if (!b) return NS_E_INVAL;
+    ns_ctx* ctx = b->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (b->ran && b->timed) {
+        HIPCHK(ctx, hipEventElapsedTime(&b->last_score_ms, b->ev[1], b->ev[2]));
+        HIPCHK(ctx, hipEventElapsedTime(&b->last_total_ms, b->ev[0], b->ev[3]));
+        b->timed = false;
+    }
+    return NS_OK;
+}
+
+extern "C" int ns_batch_fetch(ns_batch* b, ns_hit* hits_out, uint32_t* nhits_out, uint64_t* found_out) {
+    if (!b) return NS_E_INVAL;
+    ns_ctx* ctx = b->ctx;
+    if (!b->ran) return fail(ctx, NS_E_STATE, "ns_batch_fetch before ns_batch_run");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    if (b->Q) {
+        if (hits_out) HIPCHK(ctx, hipMemcpyAsync(hits_out, b->o_hits, (size_t)b->Q * b->K * sizeof(Hit), hipMemcpyDeviceToHost, st));
+        if (nhits_out) HIPCHK(ctx, hipMemcpyAsync(nhits_out, b->o_nhits, (size_t)b->Q * 4, hipMemcpyDeviceToHost, st));
+        if (found_out) HIPCHK(ctx, hipMemcpyAsync(found_out, b->o_found, (size_t)b->Q * 8, hipMemcpyDeviceToHost, st));
+    }
+    return ns_batch_sync(b);
+}
+
+extern "C" int ns_batch_get_info(ns_batch* b, ns_batch_info* info) {
+    if (!b || !info) return NS_E_INVAL;
+    info->postings = b->postings;
+    info->algo_bytes = b->postings * 8;
+    info->n_queries = b->Q;
+    info->n_items = b->n_items;
+    info->n_term_refs = b->n_terms;
+    info->tile_docs = b->tile_docs;
+    info->k = b->K;
+    info->flags = b->flags;
+    info->last_score_kernel_ms = b->last_score_ms;
+    info->last_total_ms = b->last_total_ms;
+    return NS_OK;
+}
+
+extern "C" int ns_search_batch(ns_ctx* ctx, const ns_query_desc* queries, const ns_term_ref* terms, uint32_t n_queries,
+                               uint32_t k, ns_hit* hits_out, uint32_t* nhits_out, uint64_t* found_out, uint32_t flags) {
+    ns_batch* b = nullptr;
+    int rc = ns_batch_prepare(ctx, queries, terms, n_queries, k, flags, &b);
+    if (rc != NS_OK) return rc;
+    rc = ns_batch_run(b, 0);
+    if (rc == NS_OK) rc = ns_batch_fetch(b, hits_out, nhits_out, found_out);
+    ns_batch_destroy(b);
+    return rc;
+}

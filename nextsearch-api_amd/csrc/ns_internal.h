@@ -1,0 +1,65 @@
+// Device-side descriptors shared by the HIP kernels (ns_kernels.hip) and the C-ABI host code
+// (ns_api.hip).  Domain vocabulary follows the reference: segments, posting lists, terms, hits.
+#pragma once
+#include <stdint.h>
+
+namespace ns {
+
+// Untouched accumulator slot.  The reference starts every doc's score at +0.0f
+// (unordered_map value-initialisation, src/api_engine.cpp:480).  -0.0f is an exact additive
+// identity for every x != -0.0f under round-to-nearest (-0 + x == x == +0 + x), and stays
+// distinguishable from any touched slot, so "touched" costs no extra LDS state.
+static constexpr uint32_t kSentinelBits = 0x80000000u;
+
+struct DevSeg {
+    const uint2* postings;   // {docId, tf} pairs, all inverted files of the segment back to back
+    const float* norm;       // per doc: k1*((1-b) + b*(doc_len/avgdl))   (src/api_engine.cpp:478)
+    uint64_t     n_postings;
+    uint32_t     n_docs;
+    uint32_t     n_tiles;    // ceil(n_docs / tile_docs)
+};
+
+// One scored posting list of one (query, segment) term group, in query-term order.
+struct DevTerm {
+    uint64_t list_off;   // first posting (index into DevSeg::postings)
+    uint32_t count;      // LexEntry.count
+    float    idf;        // bm25_idf(N, df), computed on the host with glibc logf
+    float    weight;     // qweight
+    uint32_t seg;
+    uint32_t pad0, pad1;
+};
+
+// Work item == one workgroup of k_score: one (query, segment) term group over a range of doc tiles.
+struct DevItem {
+    uint64_t bounds_off;   // start of this group's [tile][term] boundary table
+    uint32_t query;
+    uint32_t seg;
+    uint32_t term_begin;   // into DevTerm[]
+    uint32_t term_count;
+    uint32_t tile_begin;
+    uint32_t tile_end;
+    uint32_t out_slot;     // row of the (partial or final) result arrays
+    uint32_t pad;
+};
+
+// Term group == the (query, segment) unit the boundary prepass works on.
+struct DevGroup {
+    uint64_t bounds_off;
+    uint32_t term_begin;
+    uint32_t term_count;
+    uint32_t seg;
+    uint32_t pad;
+};
+
+struct DevQuery {
+    uint32_t part_begin;   // first partial-result row of this query
+    uint32_t part_count;   // number of partial rows (work items); 0 => no scored terms
+};
+
+struct Hit {   // == ns_hit
+    float    score;
+    uint32_t seg;
+    uint32_t doc;
+};
+
+}  // namespace ns

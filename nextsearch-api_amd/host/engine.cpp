@@ -1,0 +1,210 @@
+#include "engine.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+#include "json_writer.hpp"
+#include "textutil.hpp"
+
+namespace nextsearch {
+
+float bm25_idf(uint32_t N, uint32_t df) {
+    // std::log((((N - df + 0.5f) / (df + 0.5f)) + 1.0f))   src/api_engine.cpp:45-47
+    float num = (float)(uint32_t)(N - df) + 0.5f;
+    float den = (float)df + 0.5f;
+    return std::log((num / den) + 1.0f);   // float overload == glibc logf
+}
+
+Engine::Engine(int device) : device_(device) {}
+
+Engine::~Engine() {
+    release_device_segments();
+    if (ctx_) ns_ctx_destroy(ctx_);
+}
+
+void Engine::release_device_segments() {
+    if (ctx_)
+        for (ns_seg* s : dev_segs_)
+            if (s) ns_segment_release(ctx_, s);
+    dev_segs_.clear();
+}
+
+bool Engine::reload() {
+    err_.clear();
+    // manifest, else scan segments/seg_* sorted (src/api_engine.cpp:57-73)
+    std::vector<std::string> names = nsx::load_manifest(index_dir / "manifest.bin");
+    if (names.empty()) {
+        nsx::fs::path segroot = index_dir / "segments";
+        if (nsx::fs::exists(segroot) && nsx::fs::is_directory(segroot)) {
+            for (auto& e : nsx::fs::directory_iterator(segroot)) {
+                if (!e.is_directory()) continue;
+                auto name = e.path().filename().string();
+                if (name.rfind("seg_", 0) == 0) names.push_back(name);
+            }
+            std::sort(names.begin(), names.end());
+        }
+    }
+    if (names.empty()) { err_ = "no segments found under " + index_dir.string(); return false; }
+
+    std::vector<nsx::SegmentData> loaded(names.size());
+    for (size_t i = 0; i < names.size(); i++) {
+        nsx::fs::path segdir = index_dir / "segments" / names[i];
+        if (!nsx::load_segment(segdir, loaded[i])) { err_ = "failed to load segment: " + segdir.string(); return false; }
+    }
+
+    if (device_ >= 0) {
+        if (!ctx_) {
+            int rc = ns_ctx_create(device_, &ctx_);
+            if (rc != NS_OK) { err_ = std::string("ns_ctx_create: ") + ns_last_error(nullptr); ctx_ = nullptr; return false; }
+        }
+        // upload hook: once per segment, after load_segment (src/api_engine.cpp:90)
+        std::vector<ns_seg*> fresh(loaded.size(), nullptr);
+        release_device_segments();
+        for (size_t i = 0; i < loaded.size(); i++) {
+            auto& s = loaded[i];
+            if (s.doc_len.size() < s.N) s.doc_len.resize(s.N, 0);   // stats.bin N larger than docs.bin: treat missing as 0
+            int rc = ns_segment_upload(ctx_, (uint32_t)i, s.N, s.avgdl, s.doc_len.data(), s.postings.data(), s.postings.size() & ~7ull, &fresh[i]);
+            if (rc != NS_OK) {
+                err_ = std::string("ns_segment_upload: ") + ns_last_error(ctx_);
+                for (ns_seg* d : fresh) if (d) ns_segment_release(ctx_, d);
+                return false;
+            }
+        }
+        dev_segs_ = std::move(fresh);
+    }
+    seg_names = std::move(names);
+    segments = std::move(loaded);
+    return true;
+}
+
+void Engine::build_refs(const std::vector<std::string>& queries, std::vector<ns_query_desc>& qd,
+                        std::vector<ns_term_ref>& refs, std::vector<uint8_t>& usable) const {
+    qd.assign(queries.size(), ns_query_desc{0, 0});
+    usable.assign(queries.size(), 0);
+    refs.clear();
+    for (size_t q = 0; q < queries.size(); q++) {
+        std::vector<std::string> terms = base_terms(queries[q]);
+        qd[q].term_begin = (uint32_t)refs.size();
+        if (terms.empty() || segments.empty()) continue;   // src/api_engine.cpp:407
+        usable[q] = 1;
+        // weights: 1.0f per term (semantic expansion is out of scope; src/api_engine.cpp:419-421)
+        for (uint32_t sid = 0; sid < segments.size(); sid++) {
+            const auto& seg = segments[sid];
+            for (const auto& t : terms) {
+                auto it = seg.lex.find(t);
+                if (it == seg.lex.end()) continue;           // :455
+                const nsx::LexEntry& e = it->second;
+                if (e.df == 0) continue;                      // :458
+                ns_term_ref r;
+                r.seg_id = sid;
+                r.count = e.count;
+                r.byte_off = seg.list_byte_offset(e);
+                r.idf = bm25_idf(seg.N, e.df);
+                r.qweight = 1.0f;
+                refs.push_back(r);
+            }
+        }
+        qd[q].term_count = (uint32_t)refs.size() - qd[q].term_begin;
+    }
+}
+
+bool Engine::prepare(const std::vector<std::string>& queries, int k, uint32_t flags, ns_batch** out) {
+    if (!ctx_) { err_ = "no device context: this engine has no CPU scoring path"; return false; }
+    const int K = std::max(1, std::min(k, 100));   // src/api_engine.cpp:377
+    std::vector<ns_query_desc> qd;
+    std::vector<ns_term_ref> refs;
+    std::vector<uint8_t> usable;
+    build_refs(queries, qd, refs, usable);
+    int rc = ns_batch_prepare(ctx_, qd.data(), refs.data(), (uint32_t)queries.size(), (uint32_t)K, flags, out);
+    if (rc != NS_OK) { err_ = std::string("ns_batch_prepare: ") + ns_last_error(ctx_); return false; }
+    return true;
+}
+
+bool Engine::search_batch(const std::vector<std::string>& queries, int k, uint32_t flags, std::vector<SearchResult>& out) {
+    out.clear();
+    if (!ctx_) { err_ = "no device context: this engine has no CPU scoring path"; return false; }
+    const int K = std::max(1, std::min(k, 100));
+    const size_t Q = queries.size();
+    std::vector<ns_query_desc> qd;
+    std::vector<ns_term_ref> refs;
+    std::vector<uint8_t> usable;
+    build_refs(queries, qd, refs, usable);
+    std::vector<ns_hit> hits(Q * (size_t)K);
+    std::vector<uint32_t> nhits(Q);
+    std::vector<uint64_t> found(Q);
+    int rc = ns_search_batch(ctx_, qd.data(), refs.data(), (uint32_t)Q, (uint32_t)K, hits.data(), nhits.data(), found.data(), flags);
+    if (rc != NS_OK) { err_ = std::string("ns_search_batch: ") + ns_last_error(ctx_); return false; }
+    out.resize(Q);
+    for (size_t q = 0; q < Q; q++) {
+        SearchResult& r = out[q];
+        r.query = queries[q];
+        r.k = K;
+        r.segments = (int)segments.size();
+        r.has_found = usable[q] != 0;
+        if (!r.has_found) continue;
+        r.found = found[q];
+        r.hits.reserve(nhits[q]);
+        for (uint32_t i = 0; i < nhits[q]; i++) {
+            const ns_hit& h = hits[q * (size_t)K + i];
+            r.hits.push_back(SearchHit{h.score, h.seg_id, h.doc_id});
+        }
+    }
+    return true;
+}
+
+bool Engine::search_hits(const std::string& query, int k, uint32_t flags, SearchResult& out) {
+    std::vector<SearchResult> v;
+    if (!search_batch({query}, k, flags, v)) return false;
+    out = std::move(v[0]);
+    return true;
+}
+
+std::string Engine::to_json(const SearchResult& r) const {
+    std::string o;
+    o += "{\n";
+    if (r.has_found) o += "  \"found\": " + std::to_string(r.found) + ",\n";
+    o += "  \"k\": " + std::to_string(r.k) + ",\n";
+    o += "  \"query\": ";
+    json_escape(o, r.query);
+    o += ",\n";
+    if (r.hits.empty()) {
+        o += "  \"results\": [],\n";
+    } else {
+        o += "  \"results\": [\n";
+        for (size_t i = 0; i < r.hits.size(); i++) {
+            const SearchHit& h = r.hits[i];
+            o += "    {\n";
+            o += "      \"cord_uid\": ";
+            const auto& seg = segments[h.seg];
+            json_escape(o, h.doc < seg.cord_uid.size() ? seg.cord_uid[h.doc] : std::string());
+            o += ",\n";
+            o += "      \"docId\": " + std::to_string(h.doc) + ",\n";
+            o += "      \"score\": ";
+            json_number_from_float(o, h.score);
+            o += ",\n";
+            o += "      \"segment\": ";
+            json_escape(o, seg_names[h.seg]);
+            o += "\n";
+            o += (i + 1 < r.hits.size()) ? "    },\n" : "    }\n";
+        }
+        o += "  ],\n";
+    }
+    o += "  \"segments\": " + std::to_string(r.segments) + "\n";
+    o += "}";
+    return o;
+}
+
+std::string Engine::search(const std::string& query, int k) {
+    SearchResult r;
+    if (!search_hits(query, k, NS_FLAG_OR, r)) {
+        // the reference lets exceptions reach the HTTP layer's 500 handler (src/api_server.cpp:76-84)
+        std::string o = "{\n  \"error\": ";
+        json_escape(o, err_);
+        o += "\n}";
+        return o;
+    }
+    return to_json(r);
+}
+
+}  // namespace nextsearch

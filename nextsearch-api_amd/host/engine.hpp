@@ -1,0 +1,80 @@
+// Host facade mirroring the reference's cord19::Engine query interface
+// (include/api_engine.hpp:23-91): reload() and search(query, k) -> JSON keep their names, argument
+// meaning and error behaviour; search_batch() is additive (a batch == Q independent searches).
+//
+// What stays on the host (reference file:line):
+//   tokenise / stop-word filter      include/textutil.hpp:13-37, src/api_engine.cpp:388-397
+//   lexicon probe per segment        src/api_engine.cpp:454-458
+//   bm25_idf via glibc logf          src/api_engine.cpp:45-47,461
+//   JSON assembly                    src/api_engine.cpp:400-404,505-536
+// What crosses the C-ABI (include/nextsearch_hip.h) to the MI355X kernels:
+//   posting traversal, BM25 term scores, accumulation, top-k, found   src/api_engine.cpp:441-504
+//
+// Out of scope here: the three LRU caches, metadata.csv decoration, semantic
+// expansion, autocomplete.  There is no CPU scoring path: without a device search*() fails.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/nextsearch_hip.h"
+#include "index_format.hpp"
+
+namespace nextsearch {
+
+struct SearchHit {
+    float score;
+    uint32_t seg;
+    uint32_t doc;
+};
+
+struct SearchResult {
+    std::string query;
+    int k = 0;               // clamped K
+    int segments = 0;
+    bool has_found = false;  // false on the early-return path (src/api_engine.cpp:407): no "found" key
+    uint64_t found = 0;
+    std::vector<SearchHit> hits;
+};
+
+// bm25_idf (src/api_engine.cpp:45-47): u32 subtraction first, then int->float, fp32 throughout.
+float bm25_idf(uint32_t N, uint32_t df);
+
+class Engine {
+public:
+    nsx::fs::path index_dir;
+    std::vector<std::string> seg_names;
+    std::vector<nsx::SegmentData> segments;
+
+    // device < 0: host-only (index + query preparation; every search call fails loudly)
+    explicit Engine(int device = 0);
+    ~Engine();
+    Engine(const Engine&) = delete;
+    Engine& operator=(const Engine&) = delete;
+
+    bool reload();                                              // include/api_engine.hpp:65
+    std::string search(const std::string& query, int k);        // include/api_engine.hpp:66 (JSON text, dump(2) layout)
+    bool search_hits(const std::string& query, int k, uint32_t flags, SearchResult& out);
+    bool search_batch(const std::vector<std::string>& queries, int k, uint32_t flags, std::vector<SearchResult>& out);
+
+    // Query preparation only: flattened term refs in the C-ABI's layout.
+    // usable[q] == 0 marks the early-return case (no base terms, or no segments).
+    void build_refs(const std::vector<std::string>& queries, std::vector<ns_query_desc>& qd,
+                    std::vector<ns_term_ref>& refs, std::vector<uint8_t>& usable) const;
+    // Staged form used by bench.py: descriptors resident on the device, caller drives ns_batch_*.
+    bool prepare(const std::vector<std::string>& queries, int k, uint32_t flags, ns_batch** out);
+
+    std::string to_json(const SearchResult& r) const;
+    ns_ctx* ctx() const { return ctx_; }
+    const std::string& last_error() const { return err_; }
+
+private:
+    void release_device_segments();
+    int device_;
+    ns_ctx* ctx_ = nullptr;
+    std::vector<ns_seg*> dev_segs_;
+    std::string err_;
+};
+
+}  // namespace nextsearch

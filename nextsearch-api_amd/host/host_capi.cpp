@@ -1,0 +1,172 @@
+// C wrappers of include/nextsearch_host.h over nextsearch::Engine.
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/nextsearch_host.h"
+#include "engine.hpp"
+#include "gen_index.hpp"
+#include "textutil.hpp"
+
+struct nsh_engine {
+    nextsearch::Engine eng;
+    std::string err;
+    explicit nsh_engine(int device) : eng(device) {}
+};
+
+static std::vector<std::string> to_vec(const char* const* qs, uint32_t n) {
+    std::vector<std::string> v(n);
+    for (uint32_t i = 0; i < n; i++) v[i] = qs[i] ? qs[i] : "";
+    return v;
+}
+
+extern "C" int nsh_gen_index(const char* index_dir, uint32_t n_segments, uint32_t docs_per_segment, uint32_t vocab,
+                             uint64_t seed, int legacy_layout, uint64_t* total_postings_out) {
+    try {
+        nsx::GenParams p;
+        p.index_dir = index_dir;
+        p.n_segments = n_segments;
+        p.docs_per_segment = docs_per_segment;
+        p.vocab = vocab;
+        p.seed = seed;
+        p.legacy_layout = legacy_layout != 0;
+        nsx::GenStats st = nsx::generate_index(p);
+        if (total_postings_out) *total_postings_out = st.total_postings;
+        return 0;
+    } catch (const std::exception&) {
+        return -1;
+    }
+}
+
+extern "C" int nsh_engine_open(const char* index_dir, int device, nsh_engine** out) {
+    if (!out) return -1;
+    nsh_engine* e = new nsh_engine(device);
+    e->eng.index_dir = index_dir ? index_dir : "";
+    *out = e;
+    if (!e->eng.reload()) { e->err = e->eng.last_error(); return -1; }
+    return 0;
+}
+
+extern "C" void nsh_engine_close(nsh_engine* e) { delete e; }
+extern "C" const char* nsh_engine_error(nsh_engine* e) {
+    if (!e) return "null engine";
+    if (!e->eng.last_error().empty()) e->err = e->eng.last_error();
+    return e->err.c_str();
+}
+extern "C" ns_ctx* nsh_engine_ctx(nsh_engine* e) { return e ? e->eng.ctx() : nullptr; }
+extern "C" uint32_t nsh_engine_num_segments(nsh_engine* e) { return e ? (uint32_t)e->eng.segments.size() : 0; }
+extern "C" const char* nsh_engine_segment_name(nsh_engine* e, uint32_t seg) {
+    return (e && seg < e->eng.seg_names.size()) ? e->eng.seg_names[seg].c_str() : "";
+}
+
+extern "C" int nsh_engine_segment_info(nsh_engine* e, uint32_t seg, uint32_t* n_docs, float* avgdl, uint64_t* n_postings,
+                                       uint32_t* n_terms, int* use_barrels) {
+    if (!e || seg >= e->eng.segments.size()) return -1;
+    const auto& s = e->eng.segments[seg];
+    if (n_docs) *n_docs = s.N;
+    if (avgdl) *avgdl = s.avgdl;
+    if (n_postings) *n_postings = s.postings.size() / 8;
+    if (n_terms) *n_terms = (uint32_t)s.lex.size();
+    if (use_barrels) *use_barrels = s.use_barrels ? 1 : 0;
+    return 0;
+}
+
+extern "C" const uint32_t* nsh_engine_segment_doc_len(nsh_engine* e, uint32_t seg) {
+    return (e && seg < e->eng.segments.size()) ? e->eng.segments[seg].doc_len.data() : nullptr;
+}
+extern "C" const void* nsh_engine_segment_postings(nsh_engine* e, uint32_t seg, uint64_t* nbytes) {
+    if (!e || seg >= e->eng.segments.size()) return nullptr;
+    if (nbytes) *nbytes = e->eng.segments[seg].postings.size();
+    return e->eng.segments[seg].postings.data();
+}
+
+extern "C" int nsh_engine_lookup(nsh_engine* e, uint32_t seg, const char* term, uint32_t* term_id, uint32_t* df,
+                                 uint32_t* count, uint64_t* byte_off, float* idf) {
+    if (!e || seg >= e->eng.segments.size() || !term) return 0;
+    const auto& s = e->eng.segments[seg];
+    auto it = s.lex.find(term);
+    if (it == s.lex.end()) return 0;
+    const nsx::LexEntry& le = it->second;
+    if (term_id) *term_id = le.termId;
+    if (df) *df = le.df;
+    if (count) *count = le.count;
+    if (byte_off) *byte_off = s.list_byte_offset(le);
+    if (idf) *idf = nextsearch::bm25_idf(s.N, le.df);
+    return 1;
+}
+
+extern "C" float nsh_bm25_idf(uint32_t n_docs, uint32_t df) { return nextsearch::bm25_idf(n_docs, df); }
+
+extern "C" uint32_t nsh_base_terms(const char* query, char* buf, uint32_t cap) {
+    auto terms = nextsearch::base_terms(query ? query : "");
+    std::string joined;
+    for (size_t i = 0; i < terms.size(); i++) {
+        if (i) joined.push_back(' ');
+        joined += terms[i];
+    }
+    if (buf && cap) {
+        size_t n = std::min<size_t>(joined.size(), cap - 1);
+        std::memcpy(buf, joined.data(), n);
+        buf[n] = 0;
+    }
+    return (uint32_t)terms.size();
+}
+
+extern "C" int nsh_engine_build_refs(nsh_engine* e, const char* const* queries, uint32_t n_queries, ns_query_desc* qd,
+                                     ns_term_ref* refs, uint32_t refs_cap, uint32_t* n_refs, uint8_t* usable) {
+    if (!e) return -1;
+    std::vector<ns_query_desc> q;
+    std::vector<ns_term_ref> r;
+    std::vector<uint8_t> u;
+    e->eng.build_refs(to_vec(queries, n_queries), q, r, u);
+    if (n_refs) *n_refs = (uint32_t)r.size();
+    if (qd) std::memcpy(qd, q.data(), q.size() * sizeof(ns_query_desc));
+    if (usable) std::memcpy(usable, u.data(), u.size());
+    if (r.size() > refs_cap) return 1;
+    if (refs && !r.empty()) std::memcpy(refs, r.data(), r.size() * sizeof(ns_term_ref));
+    return 0;
+}
+
+extern "C" int nsh_engine_search_json(nsh_engine* e, const char* query, int k, char** json_out) {
+    if (!e || !json_out) return -1;
+    nextsearch::SearchResult r;
+    bool ok = e->eng.search_hits(query ? query : "", k, NS_FLAG_OR, r);
+    std::string s = ok ? e->eng.to_json(r) : std::string();
+    if (!ok) { e->err = e->eng.last_error(); *json_out = nullptr; return -1; }
+    *json_out = (char*)std::malloc(s.size() + 1);
+    std::memcpy(*json_out, s.c_str(), s.size() + 1);
+    return 0;
+}
+
+extern "C" void nsh_free(void* p) { std::free(p); }
+
+extern "C" int nsh_engine_search_batch(nsh_engine* e, const char* const* queries, uint32_t n_queries, int k, uint32_t flags,
+                                       ns_hit* hits, uint32_t* nhits, uint64_t* found, uint8_t* has_found) {
+    if (!e) return -1;
+    std::vector<nextsearch::SearchResult> res;
+    if (!e->eng.search_batch(to_vec(queries, n_queries), k, flags, res)) { e->err = e->eng.last_error(); return -1; }
+    const uint32_t K = (uint32_t)std::max(1, std::min(k, 100));
+    for (uint32_t q = 0; q < n_queries; q++) {
+        const auto& r = res[q];
+        if (nhits) nhits[q] = (uint32_t)r.hits.size();
+        if (found) found[q] = r.found;
+        if (has_found) has_found[q] = r.has_found ? 1 : 0;
+        if (hits) {
+            for (uint32_t i = 0; i < K; i++) {
+                ns_hit h;
+                if (i < r.hits.size()) { h.score = r.hits[i].score; h.seg_id = r.hits[i].seg; h.doc_id = r.hits[i].doc; }
+                else { h.score = -__builtin_inff(); h.seg_id = 0xFFFFFFFFu; h.doc_id = 0xFFFFFFFFu; }
+                hits[(size_t)q * K + i] = h;
+            }
+        }
+    }
+    return 0;
+}
+
+extern "C" int nsh_engine_prepare(nsh_engine* e, const char* const* queries, uint32_t n_queries, int k, uint32_t flags,
+                                  ns_batch** out) {
+    if (!e || !out) return -1;
+    if (!e->eng.prepare(to_vec(queries, n_queries), k, flags, out)) { e->err = e->eng.last_error(); return -1; }
+    return 0;
+}

@@ -1,0 +1,330 @@
+"""ctypes bindings of the two in-tree libraries (plumbing only; no compute happens in Python).
+
+  libnextsearch_hip.so   include/nextsearch_hip.h   C-ABI of the MI355X hot path
+  libnextsearch_host.so  include/nextsearch_host.h  C wrappers of the host facade (Engine mirror)
+
+Loading fails loudly if the libraries are missing: there is no Python or CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(HERE, "libnextsearch_hip.so")
+HOST_LIB_PATH = os.path.join(HERE, "libnextsearch_host.so")
+
+NS_OK = 0
+NS_FLAG_OR = 0
+NS_FLAG_AND = 1
+NS_MAX_K = 100
+
+
+class NsTermRef(C.Structure):
+    _fields_ = [("seg_id", C.c_uint32), ("count", C.c_uint32), ("byte_off", C.c_uint64),
+                ("idf", C.c_float), ("qweight", C.c_float)]
+
+
+class NsQueryDesc(C.Structure):
+    _fields_ = [("term_begin", C.c_uint32), ("term_count", C.c_uint32)]
+
+
+class NsHit(C.Structure):
+    _fields_ = [("score", C.c_float), ("seg_id", C.c_uint32), ("doc_id", C.c_uint32)]
+
+
+class NsBatchInfo(C.Structure):
+    _fields_ = [("postings", C.c_uint64), ("algo_bytes", C.c_uint64), ("n_queries", C.c_uint32),
+                ("n_items", C.c_uint32), ("n_term_refs", C.c_uint32), ("tile_docs", C.c_uint32),
+                ("k", C.c_uint32), ("flags", C.c_uint32), ("last_score_kernel_ms", C.c_float),
+                ("last_total_ms", C.c_float)]
+
+
+HIT_DTYPE = np.dtype([("score", "<f4"), ("seg", "<u4"), ("doc", "<u4")])
+TERM_DTYPE = np.dtype([("seg_id", "<u4"), ("count", "<u4"), ("byte_off", "<u8"), ("idf", "<f4"), ("qweight", "<f4")])
+QDESC_DTYPE = np.dtype([("term_begin", "<u4"), ("term_count", "<u4")])
+assert HIT_DTYPE.itemsize == C.sizeof(NsHit) == 12
+assert TERM_DTYPE.itemsize == C.sizeof(NsTermRef) == 24
+assert QDESC_DTYPE.itemsize == C.sizeof(NsQueryDesc) == 8
+
+# every symbol include/nextsearch_hip.h declares
+HIP_SYMBOLS = [
+    "ns_ctx_create", "ns_ctx_destroy", "ns_ctx_set_stream", "ns_last_error", "ns_device_name",
+    "ns_segment_upload", "ns_segment_release", "ns_search_batch", "ns_batch_prepare",
+    "ns_batch_bind_outputs", "ns_batch_run", "ns_batch_sync", "ns_batch_fetch", "ns_batch_get_info",
+    "ns_batch_destroy", "ns_set_tuning",
+]
+HOST_SYMBOLS = [
+    "nsh_gen_index", "nsh_engine_open", "nsh_engine_close", "nsh_engine_error", "nsh_engine_ctx",
+    "nsh_engine_num_segments", "nsh_engine_segment_name", "nsh_engine_segment_info",
+    "nsh_engine_segment_doc_len", "nsh_engine_segment_postings", "nsh_engine_lookup", "nsh_bm25_idf",
+    "nsh_base_terms", "nsh_engine_build_refs", "nsh_engine_search_json", "nsh_free",
+    "nsh_engine_search_batch", "nsh_engine_prepare",
+]
+
+_hip = None
+_host = None
+
+
+def hip_lib():
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_LIB_PATH):
+            raise RuntimeError(f"{HIP_LIB_PATH} is missing: build it with `make -C nextsearch-api_amd` "
+                               "(there is no fallback path)")
+        L = C.CDLL(HIP_LIB_PATH, mode=C.RTLD_GLOBAL)
+        vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+        L.ns_ctx_create.argtypes = [i32, C.POINTER(vp)]
+        L.ns_ctx_destroy.argtypes = [vp]
+        L.ns_ctx_destroy.restype = None
+        L.ns_ctx_set_stream.argtypes = [vp, vp]
+        L.ns_last_error.argtypes = [vp]
+        L.ns_last_error.restype = C.c_char_p
+        L.ns_device_name.argtypes = [vp]
+        L.ns_device_name.restype = C.c_char_p
+        L.ns_segment_upload.argtypes = [vp, u32, u32, C.c_float, vp, vp, u64, C.POINTER(vp)]
+        L.ns_segment_release.argtypes = [vp, vp]
+        L.ns_search_batch.argtypes = [vp, vp, vp, u32, u32, vp, vp, vp, u32]
+        L.ns_batch_prepare.argtypes = [vp, vp, vp, u32, u32, u32, C.POINTER(vp)]
+        L.ns_batch_bind_outputs.argtypes = [vp, vp, vp, vp]
+        L.ns_batch_run.argtypes = [vp, i32]
+        L.ns_batch_sync.argtypes = [vp]
+        L.ns_batch_fetch.argtypes = [vp, vp, vp, vp]
+        L.ns_batch_get_info.argtypes = [vp, C.POINTER(NsBatchInfo)]
+        L.ns_batch_destroy.argtypes = [vp]
+        L.ns_batch_destroy.restype = None
+        L.ns_set_tuning.argtypes = [vp, u32, u32]
+        _hip = L
+    return _hip
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        hip_lib()
+        if not os.path.exists(HOST_LIB_PATH):
+            raise RuntimeError(f"{HOST_LIB_PATH} is missing: build it with `make -C nextsearch-api_amd`")
+        L = C.CDLL(HOST_LIB_PATH, mode=C.RTLD_GLOBAL)
+        vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+        L.nsh_gen_index.argtypes = [C.c_char_p, u32, u32, u32, u64, i32, C.POINTER(u64)]
+        L.nsh_engine_open.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
+        L.nsh_engine_close.argtypes = [vp]
+        L.nsh_engine_close.restype = None
+        L.nsh_engine_error.argtypes = [vp]
+        L.nsh_engine_error.restype = C.c_char_p
+        L.nsh_engine_ctx.argtypes = [vp]
+        L.nsh_engine_ctx.restype = vp
+        L.nsh_engine_num_segments.argtypes = [vp]
+        L.nsh_engine_num_segments.restype = u32
+        L.nsh_engine_segment_name.argtypes = [vp, u32]
+        L.nsh_engine_segment_name.restype = C.c_char_p
+        L.nsh_engine_segment_info.argtypes = [vp, u32, C.POINTER(u32), C.POINTER(C.c_float), C.POINTER(u64),
+                                              C.POINTER(u32), C.POINTER(i32)]
+        L.nsh_engine_segment_doc_len.argtypes = [vp, u32]
+        L.nsh_engine_segment_doc_len.restype = vp
+        L.nsh_engine_segment_postings.argtypes = [vp, u32, C.POINTER(u64)]
+        L.nsh_engine_segment_postings.restype = vp
+        L.nsh_engine_lookup.argtypes = [vp, u32, C.c_char_p, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32),
+                                        C.POINTER(u64), C.POINTER(C.c_float)]
+        L.nsh_bm25_idf.argtypes = [u32, u32]
+        L.nsh_bm25_idf.restype = C.c_float
+        L.nsh_base_terms.argtypes = [C.c_char_p, C.c_char_p, u32]
+        L.nsh_base_terms.restype = u32
+        L.nsh_engine_build_refs.argtypes = [vp, C.POINTER(C.c_char_p), u32, vp, vp, u32, C.POINTER(u32), vp]
+        L.nsh_engine_search_json.argtypes = [vp, C.c_char_p, i32, C.POINTER(vp)]
+        L.nsh_free.argtypes = [vp]
+        L.nsh_free.restype = None
+        L.nsh_engine_search_batch.argtypes = [vp, C.POINTER(C.c_char_p), u32, i32, u32, vp, vp, vp, vp]
+        L.nsh_engine_prepare.argtypes = [vp, C.POINTER(C.c_char_p), u32, i32, u32, C.POINTER(vp)]
+        _host = L
+    return _host
+
+
+def _cstr_array(strings):
+    arr = (C.c_char_p * len(strings))()
+    arr[:] = [s.encode("utf-8") if isinstance(s, str) else s for s in strings]
+    return arr
+
+
+def clamp_k(k):
+    return max(1, min(int(k), NS_MAX_K))
+
+
+def gen_index(index_dir, n_segments, docs_per_segment, vocab=65536, seed=1337, legacy=False):
+    total = C.c_uint64(0)
+    rc = host_lib().nsh_gen_index(index_dir.encode(), n_segments, docs_per_segment, vocab, seed, int(legacy), C.byref(total))
+    if rc != 0:
+        raise RuntimeError(f"nsh_gen_index({index_dir}) failed")
+    return total.value
+
+
+class Batch:
+    """Staged batch: descriptors resident on the device; run() enqueues one pass of the hot path."""
+
+    def __init__(self, handle, n_queries, k):
+        self.h = handle
+        self.Q = n_queries
+        self.K = k
+
+    def bind_outputs(self, d_hits, d_nhits, d_found):
+        rc = hip_lib().ns_batch_bind_outputs(self.h, d_hits, d_nhits, d_found)
+        if rc != NS_OK:
+            raise RuntimeError("ns_batch_bind_outputs failed")
+
+    def run(self, timed=False):
+        rc = hip_lib().ns_batch_run(self.h, int(timed))
+        if rc != NS_OK:
+            raise RuntimeError(f"ns_batch_run failed rc={rc}")
+
+    def sync(self):
+        rc = hip_lib().ns_batch_sync(self.h)
+        if rc != NS_OK:
+            raise RuntimeError(f"ns_batch_sync failed rc={rc}")
+
+    def fetch(self):
+        hits = np.empty((self.Q, self.K), dtype=HIT_DTYPE)
+        nhits = np.empty(self.Q, dtype=np.uint32)
+        found = np.empty(self.Q, dtype=np.uint64)
+        rc = hip_lib().ns_batch_fetch(self.h, hits.ctypes.data, nhits.ctypes.data, found.ctypes.data)
+        if rc != NS_OK:
+            raise RuntimeError(f"ns_batch_fetch failed rc={rc}")
+        return hits, nhits, found
+
+    def info(self):
+        inf = NsBatchInfo()
+        hip_lib().ns_batch_get_info(self.h, C.byref(inf))
+        return inf
+
+    def close(self):
+        if self.h:
+            hip_lib().ns_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+class Engine:
+    """Python view of the host facade (mirror of cord19::Engine: reload at open, search, search_batch)."""
+
+    def __init__(self, index_dir, device=0):
+        self._L = host_lib()
+        h = C.c_void_p()
+        rc = self._L.nsh_engine_open(index_dir.encode(), device, C.byref(h))
+        self.h = h
+        if rc != 0:
+            msg = self._L.nsh_engine_error(h).decode()
+            self._L.nsh_engine_close(h)
+            self.h = None
+            raise RuntimeError(f"Engine.reload failed: {msg}")
+        self.device = device
+
+    def close(self):
+        if self.h:
+            self._L.nsh_engine_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def error(self):
+        return self._L.nsh_engine_error(self.h).decode()
+
+    @property
+    def ctx(self):
+        return self._L.nsh_engine_ctx(self.h)
+
+    @property
+    def num_segments(self):
+        return self._L.nsh_engine_num_segments(self.h)
+
+    def segment_name(self, seg):
+        return self._L.nsh_engine_segment_name(self.h, seg).decode()
+
+    def segment_info(self, seg):
+        n, a, p, t, b = C.c_uint32(), C.c_float(), C.c_uint64(), C.c_uint32(), C.c_int()
+        rc = self._L.nsh_engine_segment_info(self.h, seg, C.byref(n), C.byref(a), C.byref(p), C.byref(t), C.byref(b))
+        if rc != 0:
+            raise IndexError(seg)
+        return {"n_docs": n.value, "avgdl": a.value, "n_postings": p.value, "n_terms": t.value, "use_barrels": bool(b.value)}
+
+    def segment_doc_len(self, seg):
+        n = self.segment_info(seg)["n_docs"]
+        p = self._L.nsh_engine_segment_doc_len(self.h, seg)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(n,)).copy() if n else np.zeros(0, np.uint32)
+
+    def segment_postings(self, seg):
+        nb = C.c_uint64()
+        p = self._L.nsh_engine_segment_postings(self.h, seg, C.byref(nb))
+        n = nb.value // 4
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(n,)).copy().reshape(-1, 2) if n else np.zeros((0, 2), np.uint32)
+
+    def lookup(self, seg, term):
+        tid, df, cnt, off, idf = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_float()
+        ok = self._L.nsh_engine_lookup(self.h, seg, term.encode(), C.byref(tid), C.byref(df), C.byref(cnt), C.byref(off), C.byref(idf))
+        if not ok:
+            return None
+        return {"term_id": tid.value, "df": df.value, "count": cnt.value, "byte_off": off.value, "idf": idf.value}
+
+    def build_refs(self, queries):
+        Q = len(queries)
+        qarr = _cstr_array(queries)
+        qd = np.zeros(Q, dtype=QDESC_DTYPE)
+        usable = np.zeros(Q, dtype=np.uint8)
+        n = C.c_uint32(0)
+        self._L.nsh_engine_build_refs(self.h, qarr, Q, qd.ctypes.data, None, 0, C.byref(n), usable.ctypes.data)
+        refs = np.zeros(max(n.value, 1), dtype=TERM_DTYPE)
+        rc = self._L.nsh_engine_build_refs(self.h, qarr, Q, qd.ctypes.data, refs.ctypes.data, n.value, C.byref(n), usable.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("nsh_engine_build_refs failed")
+        return qd, refs[: n.value], usable
+
+    def search_json(self, query, k):
+        out = C.c_void_p()
+        rc = self._L.nsh_engine_search_json(self.h, query.encode(), k, C.byref(out))
+        if rc != 0:
+            raise RuntimeError(f"search failed: {self.error()}")
+        s = C.string_at(out).decode()
+        self._L.nsh_free(out)
+        return s
+
+    def search_batch(self, queries, k, flags=NS_FLAG_OR):
+        Q, K = len(queries), clamp_k(k)
+        hits = np.empty((Q, K), dtype=HIT_DTYPE)
+        nhits = np.zeros(Q, dtype=np.uint32)
+        found = np.zeros(Q, dtype=np.uint64)
+        has_found = np.zeros(Q, dtype=np.uint8)
+        rc = self._L.nsh_engine_search_batch(self.h, _cstr_array(queries), Q, k, flags, hits.ctypes.data,
+                                             nhits.ctypes.data, found.ctypes.data, has_found.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"search_batch failed: {self.error()}")
+        return hits, nhits, found, has_found
+
+    def prepare(self, queries, k, flags=NS_FLAG_OR):
+        b = C.c_void_p()
+        rc = self._L.nsh_engine_prepare(self.h, _cstr_array(queries), len(queries), k, flags, C.byref(b))
+        if rc != 0:
+            raise RuntimeError(f"prepare failed: {self.error()}")
+        return Batch(b, len(queries), clamp_k(k))
+
+    def set_tuning(self, variant=0, min_items=0):
+        rc = hip_lib().ns_set_tuning(self.ctx, variant, min_items)
+        if rc != NS_OK:
+            raise RuntimeError(hip_lib().ns_last_error(self.ctx).decode())
+
+
+def search_batch_raw(ctx, qd, refs, k, flags=NS_FLAG_OR):
+    """Direct call of the C-ABI's one-shot entry point with numpy descriptor arrays."""
+    L = hip_lib()
+    Q, K = len(qd), int(k)
+    hits = np.empty((Q, max(K, 1)), dtype=HIT_DTYPE)
+    nhits = np.zeros(Q, dtype=np.uint32)
+    found = np.zeros(Q, dtype=np.uint64)
+    qd = np.ascontiguousarray(qd, dtype=QDESC_DTYPE)
+    refs = np.ascontiguousarray(refs, dtype=TERM_DTYPE)
+    rc = L.ns_search_batch(ctx, qd.ctypes.data, refs.ctypes.data if len(refs) else None, Q, K, hits.ctypes.data,
+                           nhits.ctypes.data, found.ctypes.data, flags)
+    return rc, hits, nhits, found

@@ -1,0 +1,124 @@
+// TEST INFRASTRUCTURE ONLY — driver around the *real* reference engine.
+//
+// This file is ours; it #includes the reference's own headers and is linked against the
+// reference's own translation units compiled where they lie under /root/reference (see
+// oracle/Makefile, target `ref`).  No reference source is copied into this repository and the
+// resulting binary (oracle/_ref/ref_driver) is git-ignored.  It exists to
+//   (1) capture golden vectors from cord19::Engine::search (src/api_engine.cpp:369-542) that pin
+//       the C restatement in oracle/bm25_oracle.c and, through it, the HIP path;
+//   (2) serve as the `cpu_baseline.kind == "reference"` leg of bench.py (it travels to the GPU box
+//       as a prebuilt binary; /root/reference itself never does).
+//
+// Usage:
+//   ref_driver search <index_dir> <queries.txt> <K> <out.txt>
+//        one query per line; writes per query:  "Q <found|-1> <nhits>" then nhits lines
+//        "<segIdx> <docId> <score-bits-hex>"
+//   ref_driver time <index_dir> <queries.txt> <K> <max_seconds>
+//        prints one JSON line {"queries":n,"seconds":s,"qps":...}; the search-result cache is
+//        emptied after every call so search_cache.json rewrites stay O(1) (api_engine.cpp:245-249).
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <unistd.h>
+#include <vector>
+
+#include "api_engine.hpp"
+#include "api_segment.hpp"
+
+using cord19::json;
+
+static std::vector<std::string> read_lines(const std::string& path) {
+    std::vector<std::string> out;
+    std::ifstream in(path);
+    std::string line;
+    while (std::getline(in, line)) out.push_back(line);
+    return out;
+}
+
+static void drop_cache(cord19::Engine& e) {
+    e.cache.clear();
+    e.lru_list.clear();
+    e.cache_updates_since_save = 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 6) {
+        std::fprintf(stderr, "usage: %s search|time <index_dir> <queries.txt> <K> <out|max_seconds>\n", argv[0]);
+        return 2;
+    }
+    std::string mode = argv[1];
+    std::string index_dir = fs::absolute(argv[2]).string();
+    std::string qpath = fs::absolute(argv[3]).string();
+    int K = std::atoi(argv[4]);
+    std::string last = argv[5];
+    std::string outpath = (mode == "search") ? fs::absolute(last).string() : std::string();
+
+    auto queries = read_lines(qpath);
+
+    // The engine persists JSON caches into the CWD: run from a private scratch directory.
+    char tmpl[] = "/tmp/ns_ref_scratch_XXXXXX";
+    char* scratch = mkdtemp(tmpl);
+    if (!scratch || chdir(scratch) != 0) { std::perror("scratch"); return 1; }
+
+    int rc = 0;
+    {
+        cord19::Engine engine;
+        engine.index_dir = index_dir;
+        if (!engine.reload()) { std::fprintf(stderr, "reload failed for %s\n", index_dir.c_str()); return 1; }
+        drop_cache(engine);
+
+        std::unordered_map<std::string, uint32_t> seg_index;
+        for (uint32_t i = 0; i < engine.seg_names.size(); i++) seg_index[engine.seg_names[i]] = i;
+
+        if (mode == "search") {
+            std::FILE* out = std::fopen(outpath.c_str(), "w");
+            if (!out) { std::perror("out"); return 1; }
+            for (auto& q : queries) {
+                json j = engine.search(q, K);
+                drop_cache(engine);
+                long long found = -1;
+                if (j.count("found")) found = (long long)j["found"].get<uint64_t>();
+                auto& res = j["results"];
+                std::fprintf(out, "Q %lld %zu\n", found, res.size());
+                for (auto& r : res) {
+                    float s = (float)r["score"].get<double>();
+                    uint32_t bits;
+                    std::memcpy(&bits, &s, 4);
+                    uint32_t seg = seg_index.at(r["segment"].get<std::string>());
+                    uint32_t doc = r["docId"].get<uint32_t>();
+                    std::fprintf(out, "%u %u %08x\n", seg, doc, bits);
+                }
+            }
+            std::fclose(out);
+        } else if (mode == "time") {
+            double max_s = std::atof(last.c_str());
+            auto t0 = std::chrono::steady_clock::now();
+            size_t n = 0;
+            unsigned long long sink = 0;
+            for (auto& q : queries) {
+                json j = engine.search(q, K);
+                drop_cache(engine);
+                if (j.count("found")) sink += j["found"].get<uint64_t>();
+                n++;
+                double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (el > max_s) break;
+            }
+            double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            std::printf("{\"queries\": %zu, \"seconds\": %.6f, \"qps\": %.6f, \"found_sum\": %llu}\n",
+                        n, el, n / el, sink);
+        } else {
+            rc = 2;
+        }
+        drop_cache(engine);  // destructor saves caches; keep that trivial
+    }
+    // best-effort cleanup of the scratch directory
+    std::remove("search_cache.json");
+    std::remove("ai_overview_cache.json");
+    std::remove("ai_summary_cache.json");
+    if (chdir("/") == 0) rmdir(scratch);
+    return rc;
+}
