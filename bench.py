@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py — queries/sec of the MI355X BM25 hot path + fraction of the HBM roofline.
+
+A "step" is one pass of the hot path (k_bounds -> k_score -> [k_merge]) over one batch of synthetic
+queries whose descriptors and index are already resident in HBM, plus — for N > 1 — the one RCCL
+all-gather of the fixed-size result blocks.  Default workload = BASELINE config 5's query law
+(Zipf-skewed 1-8 term mix, K=10, OR) over the 1M-doc synthetic CORD-19-shaped index, 16384 queries
+per GPU (weak scaling: every rank scores its own 16384-query batch against a replicated index).
+
+    python bench.py [--gpus N --steps K --warmup W] [--config cfg5|cfg3|cfg4|cfg2] [--variant V]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (scoring kernel:
+algorithmic bytes per launch / HIP-event duration, vs 8 TB/s) and, at N=1, `cpu_baseline`
+(the REAL reference engine, oracle/_ref/ref_driver, timed on this box's host on a bounded sample).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "nextsearch-api_amd")
+sys.path.insert(0, PKG)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg5", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
+    ap.add_argument("--queries", type=int, default=0, help="queries per GPU (0 = the config's batch)")
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--min-items", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--index-dir", default="", help="reuse/generate the index here instead of a temp dir")
+    return ap.parse_args()
+
+
+def cpu_baseline(index_dir, queries, k, budget_s):
+    """Reference engine (kind=reference) or, if its binary is absent, the oracle port, on ONE host
+    thread — the reference serialises every search behind Engine::mtx (src/api_engine.cpp:372)."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    port = os.path.join(ROOT, "oracle", "bm25_oracle_cli")
+    with tempfile.TemporaryDirectory(prefix="ns_cpu_") as tmp:
+        qpath = os.path.join(tmp, "q.txt")
+        sample = queries[:4096]
+        with open(qpath, "w") as f:
+            f.write("\n".join(sample) + "\n")
+        for kind, exe in (("reference", ref), ("port", port)):
+            if not os.path.exists(exe):
+                continue
+            try:
+                cmd = [exe, "time", index_dir, qpath, str(k), str(budget_s)] + (["1"] if kind == "port" else [])
+                out = subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=budget_s * 4 + 120).stdout
+                r = json.loads(out.strip().splitlines()[-1])
+                return {"value": r["qps"], "unit": "queries/s", "cores": 1, "kind": kind,
+                        "sample": f"first {r['queries']} queries of the same workload, {r['seconds']:.1f} s, "
+                                  + ("cord19::Engine::search built -O2 from the reference sources (search cache emptied per call)"
+                                     if kind == "reference" else "oracle/bm25_oracle.c, 1 thread")}
+            except Exception as e:   # noqa: BLE001
+                sys.stderr.write(f"[bench] cpu baseline via {exe} failed: {e}\n")
+    return None
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        sys.stderr.write(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE\n")
+    n_gpus = max(world, 1)
+
+    import numpy as np
+    import torch
+
+    import nsbind
+    import shard
+    import workloads
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (there is no CPU path); torch.cuda.is_available() is False")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if n_gpus > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    gen, q_default, K, flags, (nseg, docs) = workloads.WORKLOADS[args.config]
+    Q = args.queries or q_default
+    seed = {"cfg2": 2002, "cfg3": 2003, "cfg4": 2004, "cfg5": 2005}[args.config]
+    # weak scaling: each rank owns a full batch of its own (different seed), index replicated
+    queries = gen(Q, seed + 7919 * rank)
+
+    tmp = None
+    if args.index_dir:
+        index_dir = args.index_dir
+        if rank == 0 and not os.path.exists(os.path.join(index_dir, "manifest.bin")):
+            nsbind.gen_index(index_dir, nseg, docs, 65536, 1337, False)
+        if dist is not None:
+            dist.barrier()
+    else:
+        tmp = tempfile.TemporaryDirectory(prefix=f"ns_bench_r{rank}_")
+        index_dir = os.path.join(tmp.name, "index")
+        nsbind.gen_index(index_dir, nseg, docs, 65536, 1337, False)
+
+    eng = nsbind.Engine(index_dir, local_rank)
+    stream = torch.cuda.current_stream()
+    nsbind.hip_lib().ns_ctx_set_stream(eng.ctx, stream.cuda_stream)
+    eng.set_tuning(args.variant, args.min_items)
+
+    batch = eng.prepare(queries, K, flags)
+    l_hits = torch.zeros((Q, K, 3), dtype=torch.int32, device="cuda")
+    l_nhits = torch.zeros(Q, dtype=torch.int32, device="cuda")
+    l_found = torch.zeros(Q, dtype=torch.int64, device="cuda")
+    batch.bind_outputs(l_hits.data_ptr(), l_nhits.data_ptr(), l_found.data_ptr())
+    gathered = None
+    if dist is not None:
+        gathered = (torch.empty((n_gpus * Q, K, 3), dtype=torch.int32, device="cuda"),
+                    torch.empty(n_gpus * Q, dtype=torch.int32, device="cuda"),
+                    torch.empty(n_gpus * Q, dtype=torch.int64, device="cuda"))
+
+    def step(timed):
+        batch.run(timed=timed)
+        if dist is not None:
+            shard.gather_results(l_hits, l_nhits, l_found, out=gathered)
+
+    for _ in range(args.warmup):
+        step(False)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    batch.sync()   # reads the HIP events recorded on the stream during the timed region
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    info = batch.info()
+    # sanity: results of the timed region are real
+    nh = l_nhits.cpu().numpy()
+    fd = l_found.cpu().numpy()
+    assert (nh == np.minimum(fd, K)).all(), "result sanity check failed"
+
+    if rank == 0:
+        score_ms = info.sum_score_kernel_ms / max(info.timed_runs, 1)
+        total_ms = info.sum_total_ms / max(info.timed_runs, 1)
+        achieved = info.algo_bytes / (score_ms * 1e-3) / 1e9 if score_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as f:
+                    tj = json.load(f)
+                traffic = tj.get(f"{args.config}_v{args.variant}_q{Q}")
+            except Exception:   # noqa: BLE001
+                traffic = None
+        line = {
+            "metric": "queries/sec at k=10 over 1M-doc index; achieved HBM GB/s vs peak" if args.config in ("cfg5", "cfg4")
+                      else f"queries/sec ({args.config})",
+            "value": n_gpus * Q * args.steps / elapsed,
+            "unit": "queries/s",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": {"cfg5": "BASELINE config 5 query law: 1-8 terms (1+Poisson(2)), 30% hot ranks [1,32] / 70% log-uniform tail, OR, k=10",
+                             "cfg3": "BASELINE config 3: 5-term disjunctive, rank~1/r on [1,5000], k=100",
+                             "cfg4": "BASELINE config 4: cfg3 law over 8 x 125k-doc segments, k=10",
+                             "cfg2": "BASELINE config 2: 2-term conjunctive (AND extension), ranks U[10,1000], k=10, 100k docs"}[args.config],
+                "index": f"{nseg} segment(s) x {docs} docs, 65536-term Zipf vocabulary, {info.postings / max(Q,1):.0f} postings/query",
+                "queries_per_gpu": Q,
+                "global_batch": n_gpus * Q,
+                "k": K,
+                "parallelism": f"query-sharded x{n_gpus}, index replicated" + (", RCCL all-gather of results per step" if n_gpus > 1 else ""),
+                "kernel_variant": args.variant,
+                "tile_docs": info.tile_docs,
+                "work_items": info.n_items,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_score",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "algo_bytes_per_launch": int(info.algo_bytes),
+                "kernel_ms": score_ms,
+                "all_kernels_ms": total_ms,
+            },
+        }
+        if n_gpus == 1 and args.cpu_seconds > 0:
+            cb = cpu_baseline(index_dir, queries, K, args.cpu_seconds)
+            if cb is not None:
+                line["cpu_baseline"] = cb
+        print(json.dumps(line), flush=True)
+
+    batch.close()
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if tmp is not None:
+        tmp.cleanup()
+
+
+if __name__ == "__main__":
+    main()

@@ -80,6 +80,10 @@ typedef struct ns_batch_info {
     uint32_t flags;
     float    last_score_kernel_ms; /* HIP-event time of the scoring kernel in the last timed run, <0 if none */
     float    last_total_ms;        /* HIP-event time of all kernels of the last timed run, <0 if none */
+    uint32_t timed_runs;           /* timed runs accumulated since prepare (read back at every sync) */
+    uint32_t reserved;
+    double   sum_score_kernel_ms;  /* sum over timed runs of the scoring kernel's HIP-event time */
+    double   sum_total_ms;         /* sum over timed runs of first-kernel-start .. last-kernel-end */
 } ns_batch_info;
 
 /* ---- context ------------------------------------------------------------------------------ */

@@ -256,9 +256,13 @@ struct ns_batch {
     Hit* o_hits = nullptr;
     uint32_t* o_nhits = nullptr;
     uint64_t* o_found = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool ran = false, timed = false;
+    // timed runs: four events per run (start, after k_bounds, after k_score, end), read back at sync
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_pending = 0;          // events recorded since the last sync
+    bool ran = false;
     float last_score_ms = -1.0f, last_total_ms = -1.0f;
+    double sum_score_ms = 0.0, sum_total_ms = 0.0;
+    uint32_t timed_runs = 0;
 };
 
 extern "C" void ns_batch_destroy(ns_batch* b) {
@@ -269,7 +273,7 @@ extern "C" void ns_batch_destroy(ns_batch* b) {
     (void)hipFree(b->d_segs); (void)hipFree(b->d_bounds); (void)hipFree(b->d_part_hits); (void)hipFree(b->d_part_nhits);
     (void)hipFree(b->d_part_found); (void)hipFree(b->d_heads); (void)hipFree(b->d_hits); (void)hipFree(b->d_nhits);
     (void)hipFree(b->d_found);
-    for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : b->ev_pool) if (e) (void)hipEventDestroy(e);
     delete b;
 }
 
@@ -432,7 +436,6 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
         chk(hipMalloc((void**)&b->d_part_found, Pn * 8));
         chk(hipMalloc((void**)&b->d_heads, Pn * 4));
     }
-    for (auto& ev : b->ev) chk(hipEventCreate(&ev));
     if (e != hipSuccess) {
         int rc = fail(ctx, e == hipErrorOutOfMemory ? NS_E_NOMEM : NS_E_HIP, "ns_batch_prepare: %s", hipGetErrorString(e));
         ns_batch_destroy(b);
@@ -457,10 +460,20 @@ extern "C" int ns_batch_run(ns_batch* b, int timed) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const bool and_mode = (b->flags & NS_FLAG_AND) != 0;
-    if (timed) HIPCHK(ctx, hipEventRecord(b->ev[0], st));
+    hipEvent_t* ev = nullptr;
+    if (timed) {
+        while (b->ev_pool.size() < b->ev_pending + 4) {
+            hipEvent_t e = nullptr;
+            HIPCHK(ctx, hipEventCreate(&e));
+            b->ev_pool.push_back(e);
+        }
+        ev = b->ev_pool.data() + b->ev_pending;
+        b->ev_pending += 4;
+    }
+    if (timed) HIPCHK(ctx, hipEventRecord(ev[0], st));
     if (b->n_groups)
         hipLaunchKernelGGL(k_bounds, dim3(b->n_groups), dim3(128), 0, st, b->d_groups, b->d_terms, b->d_segs, b->d_bounds, b->tile_docs);
-    if (timed) HIPCHK(ctx, hipEventRecord(b->ev[1], st));
+    if (timed) HIPCHK(ctx, hipEventRecord(ev[1], st));
     Hit* sh = b->direct ? b->o_hits : b->d_part_hits;
     uint32_t* sn = b->direct ? b->o_nhits : b->d_part_nhits;
     uint64_t* sf = b->direct ? b->o_found : b->d_part_found;
@@ -472,14 +485,13 @@ extern "C" int ns_batch_run(ns_batch* b, int timed) {
             default: launch_score<512, 12, 4>(and_mode, b->n_items, st, b->d_items, b->d_terms, b->d_segs, b->d_bounds, sh, sn, sf, b->K); break;
         }
     }
-    if (timed) HIPCHK(ctx, hipEventRecord(b->ev[2], st));
+    if (timed) HIPCHK(ctx, hipEventRecord(ev[2], st));
     if (!b->direct && b->Q)
         hipLaunchKernelGGL(k_merge, dim3((b->Q + 3) / 4), dim3(256), 0, st, b->d_queries, b->Q, b->d_part_hits, b->d_part_nhits,
                            b->d_part_found, b->o_hits, b->o_nhits, b->o_found, b->K, b->d_heads);
-    if (timed) HIPCHK(ctx, hipEventRecord(b->ev[3], st));
+    if (timed) HIPCHK(ctx, hipEventRecord(ev[3], st));
     HIPCHK(ctx, hipGetLastError());
     b->ran = true;
-    b->timed = timed != 0;
     return NS_OK;
 }
 
@@ -488,11 +500,14 @@ extern "C" int ns_batch_sync(ns_batch* b) {
     ns_ctx* ctx = b->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (b->ran && b->timed) {
-        HIPCHK(ctx, hipEventElapsedTime(&b->last_score_ms, b->ev[1], b->ev[2]));
-        HIPCHK(ctx, hipEventElapsedTime(&b->last_total_ms, b->ev[0], b->ev[3]));
-        b->timed = false;
+    for (size_t i = 0; i + 4 <= b->ev_pending; i += 4) {
+        HIPCHK(ctx, hipEventElapsedTime(&b->last_score_ms, b->ev_pool[i + 1], b->ev_pool[i + 2]));
+        HIPCHK(ctx, hipEventElapsedTime(&b->last_total_ms, b->ev_pool[i], b->ev_pool[i + 3]));
+        b->sum_score_ms += b->last_score_ms;
+        b->sum_total_ms += b->last_total_ms;
+        b->timed_runs++;
     }
+    b->ev_pending = 0;
     return NS_OK;
 }
 
@@ -522,6 +537,9 @@ extern "C" int ns_batch_get_info(ns_batch* b, ns_batch_info* info) {
     info->flags = b->flags;
     info->last_score_kernel_ms = b->last_score_ms;
     info->last_total_ms = b->last_total_ms;
+    info->timed_runs = b->timed_runs;
+    info->sum_score_kernel_ms = b->sum_score_ms;
+    info->sum_total_ms = b->sum_total_ms;
     return NS_OK;
 }
 

@@ -92,8 +92,10 @@ __device__ __forceinline__ void wg_bitonic_desc(uint64_t* a, uint32_t P) {
 
 // Sort the candidate buffer, keep the best min(n, K), raise theta to the K-th best.
 // Must be called by all threads with all prior candidate writes visible (after a barrier).
+// Returns the new candidate count, computed identically by every thread (callers must not re-read
+// *s_cnt next to code that appends: a fast thread's append would be seen by a slow thread's read).
 template <int NT, int CAP>
-__device__ __noinline__ void wg_shrink(uint64_t* cand, uint32_t* s_cnt, float* s_theta, uint32_t K) {
+__device__ __noinline__ uint32_t wg_shrink(uint64_t* cand, uint32_t* s_cnt, float* s_theta, uint32_t K) {
     const uint32_t n = *s_cnt;
     uint32_t P = 2;
     while (P < n) P <<= 1;
@@ -107,6 +109,7 @@ __device__ __noinline__ void wg_shrink(uint64_t* cand, uint32_t* s_cnt, float* s
         }
     }
     __syncthreads();
+    return n >= K ? K : n;
 }
 
 // NT   threads per workgroup (multiple of 64)
@@ -295,6 +298,9 @@ __global__ void __launch_bounds__(NT) k_score(const DevItem* __restrict__ items,
             }
         }
         const float theta = s_theta;
+        // s_cnt only changes in the append phase below and in wg_shrink: snapshot it here, where it
+        // is stable, NOT after the barrier (another thread may already be appending by then).
+        const uint32_t cnt0 = s_cnt;
         uint32_t qmask = 0;
 #pragma unroll
         for (int j = 0; j < SPT; j++)
@@ -313,7 +319,7 @@ __global__ void __launch_bounds__(NT) k_score(const DevItem* __restrict__ items,
             }
         }
         __syncthreads();
-        const uint32_t cnt0 = s_cnt, nqual = s_qual;
+        const uint32_t nqual = s_qual;   // complete after the barrier; reset only after the end-of-tile barrier
         if (cnt0 + nqual <= (uint32_t)CAP) {
             // fast path: everything above theta fits
             if (qmask) {
@@ -332,8 +338,10 @@ __global__ void __launch_bounds__(NT) k_score(const DevItem* __restrict__ items,
             // ">=" (not ">") because a shrink inside the tile may have set theta from docs with
             // larger ids than later sub-batches hold; the sort's docId tie-break settles those.
             for (int sb = 0; sb < SPT; sb++) {
-                __syncthreads();
-                if (s_cnt + (uint32_t)NT > (uint32_t)CAP) wg_shrink<NT, CAP>(cand, &s_cnt, &s_theta, K);
+                __syncthreads();                 // appends of the previous sub-batch are complete
+                const uint32_t c = s_cnt;
+                __syncthreads();                 // everyone has read c before anyone appends again
+                if (c + (uint32_t)NT > (uint32_t)CAP) wg_shrink<NT, CAP>(cand, &s_cnt, &s_theta, K);
                 const float th = s_theta;
                 uint32_t sl = (uint32_t)sb * NT + tid;
                 float sv = acc[sl];
@@ -360,7 +368,8 @@ __global__ void __launch_bounds__(NT) k_score(const DevItem* __restrict__ items,
         }
         __syncthreads();
         if (tid == 0) s_qual = 0;
-        if (s_cnt > (uint32_t)(CAP / 2)) wg_shrink<NT, CAP>(cand, &s_cnt, &s_theta, K);   // uniform
+        // uniform: nothing appends between this barrier and the next tile's append phase
+        if (s_cnt > (uint32_t)(CAP / 2)) wg_shrink<NT, CAP>(cand, &s_cnt, &s_theta, K);
     }
 
     // ---- final selection for this work item ----

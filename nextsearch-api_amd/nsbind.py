@@ -37,7 +37,8 @@ class NsBatchInfo(C.Structure):
     _fields_ = [("postings", C.c_uint64), ("algo_bytes", C.c_uint64), ("n_queries", C.c_uint32),
                 ("n_items", C.c_uint32), ("n_term_refs", C.c_uint32), ("tile_docs", C.c_uint32),
                 ("k", C.c_uint32), ("flags", C.c_uint32), ("last_score_kernel_ms", C.c_float),
-                ("last_total_ms", C.c_float)]
+                ("last_total_ms", C.c_float), ("timed_runs", C.c_uint32), ("reserved", C.c_uint32),
+                ("sum_score_kernel_ms", C.c_double), ("sum_total_ms", C.c_double)]
 
 
 HIT_DTYPE = np.dtype([("score", "<f4"), ("seg", "<u4"), ("doc", "<u4")])

@@ -1,0 +1,171 @@
+"""CPU-only tests: on-disk format, generator, host-side query preparation, and that the C-ABI
+libraries load and export every symbol the headers declare.  No compute call is made here — the
+product has no CPU scoring path, and the test below asserts that it fails loudly without a GPU."""
+import ctypes as C
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+import nsbind
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header, prefix):
+    with open(os.path.join(ROOT, "include", header)) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(" + prefix + r"\w+)\s*\(", text)))
+
+
+def test_abi_exports_every_declared_symbol():
+    hip, host = nsbind.hip_lib(), nsbind.host_lib()
+    declared = _declared("nextsearch_hip.h", "ns_")
+    assert sorted(nsbind.HIP_SYMBOLS) == declared
+    for s in declared:
+        assert getattr(hip, s) is not None
+    declared_h = _declared("nextsearch_host.h", "nsh_")
+    assert sorted(nsbind.HOST_SYMBOLS) == declared_h
+    for s in declared_h:
+        assert getattr(host, s) is not None
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(nsbind.NsTermRef) == 24 and nsbind.NsTermRef.byte_off.offset == 8
+    assert C.sizeof(nsbind.NsHit) == 12 and C.sizeof(nsbind.NsQueryDesc) == 8
+    assert nsbind.NsBatchInfo.sum_score_kernel_ms.offset % 8 == 0
+
+
+def test_no_cpu_fallback(gpu_available, golden_index):
+    """Without a device the product fails loudly: ctx creation errors out and the facade refuses to search."""
+    if gpu_available:
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    rc = nsbind.hip_lib().ns_ctx_create(0, C.byref(h))
+    assert rc == -2 and not h.value
+    assert b"no CPU fallback" in nsbind.hip_lib().ns_last_error(None)
+    _, d, _ = golden_index("small2")
+    with pytest.raises(RuntimeError, match="ns_ctx_create"):
+        nsbind.Engine(d, 0)
+    eng = nsbind.Engine(d, -1)   # host-only: index + query prep
+    with pytest.raises(RuntimeError, match="no device context"):
+        eng.search_batch(["covid"], 10)
+    eng.close()
+
+
+def _read_str(b, pos):
+    (n,) = struct.unpack_from("<I", b, pos)
+    return b[pos + 4 : pos + 4 + n].decode(), pos + 4 + n
+
+
+@pytest.mark.parametrize("name", ["small2", "legacy1"])
+def test_loader_matches_independent_parse_of_files(name, golden_index):
+    """Host loader (barrels flattened into one buffer + base table) vs a struct.unpack parse of the files."""
+    g, d, total = golden_index(name)
+    eng = nsbind.Engine(d, -1)
+    p = g["params"]
+    assert eng.num_segments == p["n_segments"]
+    seen = 0
+    for s in range(eng.num_segments):
+        segdir = os.path.join(d, "segments", eng.segment_name(s))
+        info = eng.segment_info(s)
+        with open(os.path.join(segdir, "stats.bin"), "rb") as f:
+            N, avgdl = struct.unpack("<If", f.read(8))
+        assert (info["n_docs"], info["avgdl"]) == (N, avgdl) and N == p["docs_per_segment"]
+        dl = eng.segment_doc_len(s)
+        assert np.float32(np.float32(int(dl.astype(np.uint64).sum())) / np.float32(N)) == np.float32(avgdl)
+        assert dl.min() >= 20 and dl.max() < 16384
+        post = eng.segment_postings(s)
+        seen += len(post)
+        assert info["use_barrels"] == (not p["legacy"])
+        lexfiles = ([("lexicon_b%03d.bin" % b, "inverted_b%03d.bin" % b) for b in range(64)] if not p["legacy"]
+                    else [("lexicon.bin", "inverted.bin")])
+        base = 0
+        nterms = 0
+        for lf, invf in lexfiles:
+            with open(os.path.join(segdir, lf), "rb") as f:
+                lb = f.read()
+            with open(os.path.join(segdir, invf), "rb") as f:
+                inv = np.frombuffer(f.read(), dtype="<u4").reshape(-1, 2)
+            (tcount,) = struct.unpack_from("<I", lb, 0)
+            pos = 4
+            for _ in range(tcount):
+                term, pos = _read_str(lb, pos)
+                tid, df, off, cnt = struct.unpack_from("<IIQI", lb, pos)
+                pos += 20
+                nterms += 1
+                e = eng.lookup(s, term)
+                assert e is not None and (e["term_id"], e["df"], e["count"]) == (tid, df, cnt)
+                assert e["byte_off"] == base + off and off % 8 == 0 and cnt == df
+                lst = post[e["byte_off"] // 8 : e["byte_off"] // 8 + cnt]
+                np.testing.assert_array_equal(lst, inv[off // 8 : off // 8 + cnt])
+                assert np.all(np.diff(lst[:, 0].astype(np.int64)) > 0) and lst[:, 0].max() < N   # docId strictly ascending
+                assert lst[:, 1].min() >= 1 and lst[:, 1].max() <= 64
+            assert pos == len(lb)
+            base += inv.size * 4
+        assert nterms == info["n_terms"]
+    assert seen == total == g["total_postings"]
+    eng.close()
+
+
+def test_tokenizer_and_base_terms():
+    L = nsbind.host_lib()
+    buf = C.create_string_buffer(256)
+
+    def bt(q):
+        n = L.nsh_base_terms(q if isinstance(q, bytes) else q.encode(), buf, 256)
+        return n, buf.value.decode()
+
+    assert bt("COVID-19: the Virus, of a vaccine!") == (4, "covid 19 virus vaccine")
+    assert bt("covid covid") == (2, "covid covid")                 # duplicates kept
+    assert bt("the a an and or of to in for on with by as is are was were be been it this that from at") == (0, "")
+    assert bt("x y z 1 2") == (0, "")                               # size() < 2 dropped
+    assert bt(b"caf\xc3\xa9 na\xefve") == (3, "caf na ve")          # bytes >= 0x80 split tokens
+    assert bt("a1b2_c3  d4") == (3, "a1b2 c3 d4")
+    assert bt("") == (0, "")
+
+
+def test_idf_matches_reference_expression():
+    L = nsbind.host_lib()
+    for N, df in [(1000, 1), (1000, 999), (1000, 1000), (1_000_000, 600_000), (5, 9), (0, 0)]:
+        num = np.float32(np.uint32((N - df) & 0xFFFFFFFF)) + np.float32(0.5)   # u32 subtraction first (wraps when df > N)
+        want = np.log(np.float32(num / (np.float32(df) + np.float32(0.5))) + np.float32(1.0), dtype=np.float32)
+        got = np.float32(L.nsh_bm25_idf(N, df))
+        assert abs(float(got) - float(want)) <= 1e-6 * max(1.0, abs(float(want)))
+
+
+def test_build_refs_layout(golden_index):
+    g, d, _ = golden_index("small2")
+    eng = nsbind.Engine(d, -1)
+    queries = ["covid virus", "the of", "zzzz", "virus covid covid"]
+    qd, refs, usable = eng.build_refs(queries)
+    assert list(usable) == [1, 0, 1, 1]
+    assert list(qd["term_count"]) == [4, 0, 0, 6]    # 2 segments x terms, segment-major
+    assert list(refs["seg_id"][:4]) == [0, 0, 1, 1]
+    c0, v0 = eng.lookup(0, "covid"), eng.lookup(0, "virus")
+    assert (refs[0]["byte_off"], refs[0]["count"]) == (c0["byte_off"], c0["count"])
+    assert (refs[1]["byte_off"], refs[1]["count"]) == (v0["byte_off"], v0["count"])
+    assert refs[0]["idf"] == np.float32(c0["idf"]) and np.all(refs["qweight"] == 1.0)
+    # query-term order inside the segment group: virus, covid, covid
+    off = qd["term_begin"][3]
+    assert [int(x) for x in refs["byte_off"][off : off + 3]] == [v0["byte_off"], c0["byte_off"], c0["byte_off"]]
+    eng.close()
+
+
+def test_generator_shapes():
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as tmp:
+        total = nsbind.gen_index(os.path.join(tmp, "i"), 1, 50_000, 4096, 1337, False)
+        eng = nsbind.Engine(os.path.join(tmp, "i"), -1)
+        n = 50_000
+        top = eng.lookup(0, "covid")            # rank 1: df target 0.6 N (Bernoulli sweep)
+        assert abs(top["count"] - 0.6 * n) < 0.02 * n
+        r100 = eng.lookup(0, "t000100")         # sparse path: 0.6 N / 100 draws, minus collisions
+        assert 0.9 * 0.006 * n < r100["count"] <= 0.006 * n
+        assert eng.lookup(0, "t004096")["count"] >= 1
+        assert eng.lookup(0, "t004097") is None
+        assert abs(total - 0.6 * n * sum(1.0 / r for r in range(1, 4097))) < 0.03 * total
+        eng.close()
