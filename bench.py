@@ -38,6 +38,7 @@ def parse_args():
     ap.add_argument("--queries", type=int, default=0, help="queries per GPU (0 = the config's batch)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--min-items", type=int, default=0)
+    ap.add_argument("--split", type=int, default=0, help="postings per work item (0 = library default)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--index-dir", default="", help="reuse/generate the index here instead of a temp dir")
     return ap.parse_args()
@@ -115,7 +116,7 @@ def main():
     eng = nsbind.Engine(index_dir, local_rank)
     stream = torch.cuda.current_stream()
     nsbind.hip_lib().ns_ctx_set_stream(eng.ctx, stream.cuda_stream)
-    eng.set_tuning(args.variant, args.min_items)
+    eng.set_tuning(args.variant, args.min_items, args.split)
 
     batch = eng.prepare(queries, K, flags)
     l_hits = torch.zeros((Q, K, 3), dtype=torch.int32, device="cuda")
@@ -200,7 +201,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_score",
+                "kernel": "k_wscore" if args.variant in (0, 5, 6, 7) else "k_score",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -211,7 +212,7 @@ def main():
                 "all_kernels_ms": total_ms,
             },
         }
-        if n_gpus == 1 and args.cpu_seconds > 0:
+        if n_gpus == 1 and args.cpu_seconds > 0 and flags == 0:
             cb = cpu_baseline(index_dir, queries, K, args.cpu_seconds)
             if cb is not None:
                 line["cpu_baseline"] = cb

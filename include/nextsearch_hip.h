@@ -130,10 +130,13 @@ int  ns_batch_fetch(ns_batch* b, ns_hit* hits_out, uint32_t* nhits_out, uint64_t
 int  ns_batch_get_info(ns_batch* b, ns_batch_info* info);
 void ns_batch_destroy(ns_batch* b);
 
-/* ---- tuning knobs (process-wide defaults; 0 = library default) ------------------------------ */
-/* variant: 0 = default, see DESIGN.md "kernel variants".  min_items: target number of work items
- * below which queries are split across doc ranges. */
-int  ns_set_tuning(ns_ctx* ctx, uint32_t variant, uint32_t min_items);
+/* ---- tuning knobs (per ctx; 0 = library default) --------------------------------------------- */
+/* variant: 0 = default; 5/6/7 = wave-private kernel with 256/512/1024-entry tables; 1..4 = the
+ * workgroup-tile kernel (also the fallback for term groups of more than 64 terms); see DESIGN.md
+ * "kernel variants".  min_items: number of work items below which queries are additionally split
+ * across doc ranges.  split_postings: a (query, segment) group is split into doc ranges of about
+ * this many postings each. */
+int  ns_set_tuning(ns_ctx* ctx, uint32_t variant, uint32_t min_items, uint32_t split_postings);
 
 #ifdef __cplusplus
 }

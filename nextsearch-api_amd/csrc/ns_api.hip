@@ -15,6 +15,7 @@
 #include "../../include/nextsearch_hip.h"
 #include "ns_internal.h"
 #include "ns_kernels.hip"
+#include "ns_wave_kernel.hip"
 
 using namespace ns;
 
@@ -27,7 +28,8 @@ struct ns_seg {
     uint32_t n_docs = 0;
     uint64_t n_postings = 0;
     uint2* d_postings = nullptr;
-    float* d_norm = nullptr;
+    float* d_norm = nullptr;    // per doc
+    float* d_pnorm = nullptr;   // per posting
 };
 
 struct ns_ctx {
@@ -40,6 +42,7 @@ struct ns_ctx {
     std::vector<ns_seg*> segs;   // indexed by seg_id
     uint32_t variant = 0;
     uint32_t min_items = 0;
+    uint32_t split_postings = 0;
 };
 
 static thread_local std::string g_create_err;
@@ -61,17 +64,34 @@ static int fail(ns_ctx* ctx, int code, const char* fmt, ...) {
             return fail((ctx), NS_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-// Kernel variants (DESIGN.md "kernel variants"): threads per workgroup, slots per thread, postings
-// per thread per round.  tile_docs = NT * SPT.
-struct VariantDesc { uint32_t nt, spt, u; };
+// Kernel variants (DESIGN.md "kernel variants").
+//   wave variants (k_wscore): hb = accumulator-table entries per wave (batch = hb/2 postings)
+//   workgroup variants (k_score, the >64-terms fallback and the round-1 baseline): threads per
+//   workgroup, slots per thread, postings per thread per round; tile_docs = nt * spt.
+struct VariantDesc { uint32_t hb; uint32_t nt, spt, u; };
 static const VariantDesc kVariants[] = {
-    {512, 12, 4},    // 0: default (same as 2)
-    {1024, 12, 4},   // 1: 12288-doc tiles, 2 workgroups/CU
-    {512, 12, 4},    // 2:  6144-doc tiles, 4 workgroups/CU
-    {256, 16, 4},    // 3:  4096-doc tiles, 7 workgroups/CU
-    {512, 16, 8},    // 4:  8192-doc tiles, 3 workgroups/CU
+    {512, 512, 12, 4},    // 0: default = wave kernel, 512-entry tables
+    {0, 1024, 12, 4},     // 1: workgroup kernel, 12288-doc tiles
+    {0, 512, 12, 4},      // 2: workgroup kernel,  6144-doc tiles
+    {0, 256, 16, 4},      // 3: workgroup kernel,  4096-doc tiles
+    {0, 512, 16, 8},      // 4: workgroup kernel,  8192-doc tiles
+    {256, 512, 12, 4},    // 5: wave kernel, 256-entry tables
+    {512, 512, 12, 4},    // 6: wave kernel, 512-entry tables
+    {1024, 512, 12, 4},   // 7: wave kernel, 1024-entry tables
 };
 static constexpr uint32_t kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+static constexpr uint32_t kWaveMaxTerms = 64;
+static constexpr uint32_t kDefaultSplitPostings = 32768;
+
+template <int HB>
+static void launch_wscore(bool and_mode, uint32_t n_items, hipStream_t st, const DevWItem* items, const DevTerm* terms,
+                          const DevSeg* segs, Hit* hits, uint32_t* nhits, uint64_t* found, uint32_t K) {
+    dim3 grid((n_items + 3) / 4), block(256);
+    if (and_mode)
+        hipLaunchKernelGGL((k_wscore<HB, true>), grid, block, 0, st, items, n_items, terms, segs, hits, nhits, found, K);
+    else
+        hipLaunchKernelGGL((k_wscore<HB, false>), grid, block, 0, st, items, n_items, terms, segs, hits, nhits, found, K);
+}
 
 template <int NT, int SPT, int U>
 static void launch_score(bool and_mode, uint32_t n_items, hipStream_t st, const DevItem* items, const DevTerm* terms,
@@ -121,6 +141,7 @@ extern "C" void ns_ctx_destroy(ns_ctx* ctx) {
         if (!s) continue;
         (void)hipFree(s->d_postings);
         (void)hipFree(s->d_norm);
+        (void)hipFree(s->d_pnorm);
         delete s;
     }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -136,11 +157,12 @@ extern "C" int ns_ctx_set_stream(ns_ctx* ctx, void* hip_stream) {
 extern "C" const char* ns_last_error(ns_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 extern "C" const char* ns_device_name(ns_ctx* ctx) { return ctx ? ctx->devname.c_str() : ""; }
 
-extern "C" int ns_set_tuning(ns_ctx* ctx, uint32_t variant, uint32_t min_items) {
+extern "C" int ns_set_tuning(ns_ctx* ctx, uint32_t variant, uint32_t min_items, uint32_t split_postings) {
     if (!ctx) return fail(nullptr, NS_E_INVAL, "ns_set_tuning: ctx is NULL");
     if (variant >= kNumVariants) return fail(ctx, NS_E_INVAL, "unknown kernel variant %u", variant);
     ctx->variant = variant;
     ctx->min_items = min_items;
+    ctx->split_postings = split_postings;
     return NS_OK;
 }
 
@@ -160,13 +182,14 @@ extern "C" int ns_segment_upload(ns_ctx* ctx, uint32_t seg_id, uint32_t n_docs, 
     s->id = seg_id;
     s->n_docs = n_docs;
     s->n_postings = nbytes / 8;
-    auto cleanup = [&]() { (void)hipFree(s->d_postings); (void)hipFree(s->d_norm); delete s; };
+    auto cleanup = [&]() { (void)hipFree(s->d_postings); (void)hipFree(s->d_norm); (void)hipFree(s->d_pnorm); delete s; };
 
     hipError_t e;
     uint32_t* d_len = nullptr;
     // +16 B slack so vector loads at the tail stay inside the allocation
     if ((e = hipMalloc((void**)&s->d_postings, nbytes + 16)) != hipSuccess) { cleanup(); return fail(ctx, NS_E_NOMEM, "hipMalloc postings (%llu B): %s", (unsigned long long)nbytes, hipGetErrorString(e)); }
     if ((e = hipMalloc((void**)&s->d_norm, (size_t)std::max<uint32_t>(n_docs, 1) * 4)) != hipSuccess) { cleanup(); return fail(ctx, NS_E_NOMEM, "hipMalloc norm: %s", hipGetErrorString(e)); }
+    if ((e = hipMalloc((void**)&s->d_pnorm, std::max<uint64_t>(nbytes / 2, 4))) != hipSuccess) { cleanup(); return fail(ctx, NS_E_NOMEM, "hipMalloc per-posting norms (%llu B): %s", (unsigned long long)(nbytes / 2), hipGetErrorString(e)); }
     if ((e = hipMalloc((void**)&d_len, (size_t)std::max<uint32_t>(n_docs, 1) * 4)) != hipSuccess) { cleanup(); return fail(ctx, NS_E_NOMEM, "hipMalloc doc_len: %s", hipGetErrorString(e)); }
 
     // pinned, double-buffered staging: host memcpy of chunk i+1 overlaps the DMA of chunk i
@@ -202,6 +225,11 @@ extern "C" int ns_segment_upload(ns_ctx* ctx, uint32_t seg_id, uint32_t n_docs, 
             hipLaunchKernelGGL(k_norm, dim3((n_docs + 255) / 256), dim3(256), 0, ctx->stream, d_len, s->d_norm, n_docs, avgdl);
             e = hipGetLastError();
         }
+        if (e == hipSuccess && s->n_postings) {
+            uint32_t blocks = (uint32_t)std::min<uint64_t>((s->n_postings + 255) / 256, 65536);
+            hipLaunchKernelGGL(k_pnorm, dim3(blocks), dim3(256), 0, ctx->stream, s->d_postings, s->d_norm, s->d_pnorm, s->n_postings, n_docs);
+            e = hipGetLastError();
+        }
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     }
     for (int i = 0; i < 2; i++) {
@@ -225,6 +253,7 @@ extern "C" int ns_segment_release(ns_ctx* ctx, ns_seg* seg) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     (void)hipFree(seg->d_postings);
     (void)hipFree(seg->d_norm);
+    (void)hipFree(seg->d_pnorm);
     ctx->segs[seg->id] = nullptr;
     delete seg;
     return NS_OK;
@@ -234,12 +263,16 @@ extern "C" int ns_segment_release(ns_ctx* ctx, ns_seg* seg) {
 struct ns_batch {
     ns_ctx* ctx = nullptr;
     uint32_t Q = 0, K = 0, flags = 0;
-    uint32_t variant = 0, tile_docs = 0;
-    uint32_t n_items = 0, n_groups = 0, n_terms = 0, n_parts = 0;
+    uint32_t variant = 0, tile_docs = 0, hb = 0;
+    uint32_t n_items = 0;      // workgroup-kernel items (k_score)
+    uint32_t n_witems = 0;     // wave-kernel items (k_wscore)
+    uint32_t n_bgroups = 0;    // term groups that need the boundary prepass (k_score path only)
+    uint32_t n_terms = 0, n_parts = 0;
     uint64_t postings = 0;
-    bool direct = false;   // every query has exactly one work item: k_score writes final rows
+    bool direct = false;   // every query has exactly one work item: the scoring kernel writes final rows
     // device
     DevItem* d_items = nullptr;
+    DevWItem* d_witems = nullptr;
     DevTerm* d_terms = nullptr;
     DevGroup* d_groups = nullptr;
     DevQuery* d_queries = nullptr;
@@ -256,7 +289,7 @@ struct ns_batch {
     Hit* o_hits = nullptr;
     uint32_t* o_nhits = nullptr;
     uint64_t* o_found = nullptr;
-    // timed runs: four events per run (start, after k_bounds, after k_score, end), read back at sync
+    // timed runs: four events per run (start, before scoring, after scoring, end), read back at sync
     std::vector<hipEvent_t> ev_pool;
     size_t ev_pending = 0;          // events recorded since the last sync
     bool ran = false;
@@ -269,10 +302,10 @@ extern "C" void ns_batch_destroy(ns_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
-    (void)hipFree(b->d_items); (void)hipFree(b->d_terms); (void)hipFree(b->d_groups); (void)hipFree(b->d_queries);
-    (void)hipFree(b->d_segs); (void)hipFree(b->d_bounds); (void)hipFree(b->d_part_hits); (void)hipFree(b->d_part_nhits);
-    (void)hipFree(b->d_part_found); (void)hipFree(b->d_heads); (void)hipFree(b->d_hits); (void)hipFree(b->d_nhits);
-    (void)hipFree(b->d_found);
+    (void)hipFree(b->d_items); (void)hipFree(b->d_witems); (void)hipFree(b->d_terms); (void)hipFree(b->d_groups);
+    (void)hipFree(b->d_queries); (void)hipFree(b->d_segs); (void)hipFree(b->d_bounds); (void)hipFree(b->d_part_hits);
+    (void)hipFree(b->d_part_nhits); (void)hipFree(b->d_part_found); (void)hipFree(b->d_heads); (void)hipFree(b->d_hits);
+    (void)hipFree(b->d_nhits); (void)hipFree(b->d_found);
     for (auto& e : b->ev_pool) if (e) (void)hipEventDestroy(e);
     delete b;
 }
@@ -298,13 +331,15 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
 
     const VariantDesc vd = kVariants[ctx->variant];
     const uint32_t tile_docs = vd.nt * vd.spt;
+    const bool wave_path = vd.hb != 0;
 
-    // per-batch segment table (n_tiles depends on the kernel variant)
+    // per-batch segment table (n_tiles depends on the workgroup-kernel variant)
     std::vector<DevSeg> segs(ctx->segs.size());
     for (size_t i = 0; i < ctx->segs.size(); i++) {
         DevSeg d{};
         if (ns_seg* s = ctx->segs[i]) {
             d.postings = s->d_postings;
+            d.pnorm = s->d_pnorm;
             d.norm = s->d_norm;
             d.n_postings = s->n_postings;
             d.n_docs = s->n_docs;
@@ -314,10 +349,9 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
     }
 
     // ---- regroup term refs by (query, segment), keeping query-term order inside each group ----
+    struct HostGroup { DevGroup g; uint32_t query; uint64_t cost; bool wave; };
     std::vector<DevTerm> dterms;
-    std::vector<DevGroup> groups;
-    std::vector<uint32_t> group_query;
-    std::vector<uint64_t> group_cost;
+    std::vector<HostGroup> groups;
     std::vector<uint32_t> qgroup_begin(n_queries + 1, 0);
     uint64_t bounds_total = 0, postings_total = 0;
     std::vector<uint32_t> seg_ids;   // scratch
@@ -336,10 +370,10 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
         }
         std::sort(seg_ids.begin(), seg_ids.end());   // segments in manifest (id) order, api_engine.cpp:441
         for (uint32_t sid : seg_ids) {
-            DevGroup g{};
-            g.term_begin = (uint32_t)dterms.size();
-            g.seg = sid;
-            uint64_t cost = 0;
+            HostGroup hg{};
+            hg.g.term_begin = (uint32_t)dterms.size();
+            hg.g.seg = sid;
+            hg.query = q;
             for (uint32_t i = 0; i < qd.term_count; i++) {
                 const ns_term_ref& r = terms[qd.term_begin + i];
                 if (r.seg_id != sid) continue;
@@ -350,79 +384,115 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                 t.weight = r.qweight;
                 t.seg = sid;
                 dterms.push_back(t);
-                cost += r.count;
+                hg.cost += r.count;
             }
-            g.term_count = (uint32_t)dterms.size() - g.term_begin;
-            if ((flags & NS_FLAG_AND) && g.term_count > 255) return fail(ctx, NS_E_INVAL, "AND mode supports at most 255 term refs per (query, segment)");
-            g.bounds_off = bounds_total;
-            bounds_total += (uint64_t)(segs[sid].n_tiles + 1) * g.term_count;
-            postings_total += cost;
-            groups.push_back(g);
-            group_query.push_back(q);
-            group_cost.push_back(cost);
+            hg.g.term_count = (uint32_t)dterms.size() - hg.g.term_begin;
+            if ((flags & NS_FLAG_AND) && hg.g.term_count > 255) return fail(ctx, NS_E_INVAL, "AND mode supports at most 255 term refs per (query, segment)");
+            hg.wave = wave_path && hg.g.term_count <= kWaveMaxTerms;
+            if (!hg.wave) {
+                hg.g.bounds_off = bounds_total;
+                bounds_total += (uint64_t)(segs[sid].n_tiles + 1) * hg.g.term_count;
+            }
+            postings_total += hg.cost;
+            groups.push_back(hg);
         }
     }
     qgroup_begin[n_queries] = (uint32_t)groups.size();
     if (bounds_total >= (1ull << 32)) return fail(ctx, NS_E_INVAL, "batch too large: %llu boundary entries; split the batch", (unsigned long long)bounds_total);
 
-    // ---- work items: one per group, or several doc-tile ranges per group for small batches ----
-    const uint32_t min_items = ctx->min_items ? ctx->min_items : (uint32_t)std::max(ctx->n_cus, 1) * 4u;
+    // ---- work items.  A group is split into doc ranges (a) so that no single worker carries more
+    // than ~split_postings postings (the longest item bounds the batch's tail), and (b) so that a
+    // small batch still fills the chip.  Partial rows of one query are contiguous; k_merge joins them.
+    const uint32_t min_items = ctx->min_items ? ctx->min_items : (uint32_t)std::max(ctx->n_cus, 1) * 8u;
+    const uint64_t split_postings = ctx->split_postings ? ctx->split_postings : kDefaultSplitPostings;
     const uint32_t G = (uint32_t)groups.size();
     uint32_t chunks_per_group = 1;
     if (G > 0 && G < min_items) chunks_per_group = (min_items + G - 1) / G;
+    struct Cost { uint64_t c; uint32_t idx; };
     std::vector<DevItem> items;
-    std::vector<uint64_t> item_cost;
+    std::vector<DevWItem> witems;
+    std::vector<Cost> item_cost, witem_cost;
+    std::vector<DevGroup> bgroups;
     std::vector<DevQuery> dq(n_queries);
+    uint32_t n_rows = 0;
     bool direct = true;
     for (uint32_t q = 0; q < n_queries; q++) {
-        dq[q].part_begin = (uint32_t)items.size();
+        dq[q].part_begin = n_rows;
         for (uint32_t gi = qgroup_begin[q]; gi < qgroup_begin[q + 1]; gi++) {
-            const DevGroup& g = groups[gi];
-            uint32_t nt = segs[g.seg].n_tiles;
-            if (nt == 0) continue;   // empty segment: nothing to score
-            uint32_t chunks = std::min(chunks_per_group, nt);
-            uint32_t per = (nt + chunks - 1) / chunks;
-            for (uint32_t tb = 0; tb < nt; tb += per) {
-                DevItem it{};
-                it.bounds_off = g.bounds_off;
-                it.query = q;
-                it.seg = g.seg;
-                it.term_begin = g.term_begin;
-                it.term_count = g.term_count;
-                it.tile_begin = tb;
-                it.tile_end = std::min(nt, tb + per);
-                it.out_slot = (uint32_t)items.size();
-                items.push_back(it);
-                item_cost.push_back(group_cost[gi] * (it.tile_end - it.tile_begin) / nt + 1);
+            const HostGroup& hg = groups[gi];
+            const DevSeg& sg = segs[hg.g.seg];
+            if (sg.n_docs == 0) continue;   // empty segment: nothing to score
+            if (hg.wave) {
+                uint64_t want = std::max<uint64_t>((hg.cost + split_postings - 1) / split_postings, chunks_per_group);
+                uint32_t ns = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want, 1), std::min<uint32_t>(sg.n_docs, 4096));
+                for (uint32_t i = 0; i < ns; i++) {
+                    DevWItem it{};
+                    it.query = q;
+                    it.seg = hg.g.seg;
+                    it.term_begin = hg.g.term_begin;
+                    it.term_count = hg.g.term_count;
+                    it.doc_lo = (uint32_t)((uint64_t)sg.n_docs * i / ns);
+                    it.doc_hi = (uint32_t)((uint64_t)sg.n_docs * (i + 1) / ns);
+                    if (it.doc_hi <= it.doc_lo) continue;
+                    it.out_slot = n_rows++;
+                    it.whole = ns == 1;
+                    witem_cost.push_back({hg.cost / ns + 1, (uint32_t)witems.size()});
+                    witems.push_back(it);
+                }
+            } else {
+                bgroups.push_back(hg.g);
+                uint32_t nt = sg.n_tiles;
+                uint32_t chunks = std::min(chunks_per_group, nt);
+                uint32_t per = (nt + chunks - 1) / chunks;
+                for (uint32_t tb = 0; tb < nt; tb += per) {
+                    DevItem it{};
+                    it.bounds_off = hg.g.bounds_off;
+                    it.query = q;
+                    it.seg = hg.g.seg;
+                    it.term_begin = hg.g.term_begin;
+                    it.term_count = hg.g.term_count;
+                    it.tile_begin = tb;
+                    it.tile_end = std::min(nt, tb + per);
+                    it.out_slot = n_rows++;
+                    item_cost.push_back({hg.cost * (it.tile_end - it.tile_begin) / nt + 1, (uint32_t)items.size()});
+                    items.push_back(it);
+                }
             }
         }
-        dq[q].part_count = (uint32_t)items.size() - dq[q].part_begin;
+        dq[q].part_count = n_rows - dq[q].part_begin;
         if (dq[q].part_count != 1) direct = false;
     }
     if (n_queries == 0) direct = false;
-    if (direct) for (auto& it : items) it.out_slot = it.query;
+    if (direct) {
+        for (auto& it : items) it.out_slot = it.query;
+        for (auto& it : witems) it.out_slot = it.query;
+    }
 
     // longest-processing-time-first launch order (workgroups are dispatched in blockIdx order)
-    std::vector<uint32_t> order(items.size());
-    std::iota(order.begin(), order.end(), 0u);
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return item_cost[a] > item_cost[b]; });
+    auto by_cost = [](const Cost& a, const Cost& b) { return a.c > b.c; };
+    std::stable_sort(item_cost.begin(), item_cost.end(), by_cost);
+    std::stable_sort(witem_cost.begin(), witem_cost.end(), by_cost);
     std::vector<DevItem> sorted_items(items.size());
-    for (size_t i = 0; i < order.size(); i++) sorted_items[i] = items[order[i]];
+    std::vector<DevWItem> sorted_witems(witems.size());
+    for (size_t i = 0; i < items.size(); i++) sorted_items[i] = items[item_cost[i].idx];
+    for (size_t i = 0; i < witems.size(); i++) sorted_witems[i] = witems[witem_cost[i].idx];
 
     ns_batch* b = new ns_batch();
     b->ctx = ctx;
     b->Q = n_queries; b->K = k; b->flags = flags;
-    b->variant = ctx->variant; b->tile_docs = tile_docs;
-    b->n_items = (uint32_t)items.size(); b->n_groups = G; b->n_terms = (uint32_t)dterms.size();
-    b->n_parts = direct ? 0 : (uint32_t)items.size();
+    b->variant = ctx->variant; b->tile_docs = tile_docs; b->hb = vd.hb;
+    b->n_items = (uint32_t)items.size(); b->n_witems = (uint32_t)witems.size();
+    b->n_bgroups = (uint32_t)bgroups.size(); b->n_terms = (uint32_t)dterms.size();
+    b->n_parts = direct ? 0 : n_rows;
     b->postings = postings_total;
     b->direct = direct;
 
     hipError_t e = hipSuccess;
     auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
     chk(dev_upload(&b->d_items, sorted_items));
+    chk(dev_upload(&b->d_witems, sorted_witems));
     chk(dev_upload(&b->d_terms, dterms));
-    chk(dev_upload(&b->d_groups, groups));
+    chk(dev_upload(&b->d_groups, bgroups));
     chk(dev_upload(&b->d_queries, dq));
     chk(dev_upload(&b->d_segs, segs));
     chk(hipMalloc((void**)&b->d_bounds, std::max<uint64_t>(bounds_total, 1) * 4));
@@ -471,19 +541,25 @@ extern "C" int ns_batch_run(ns_batch* b, int timed) {
         b->ev_pending += 4;
     }
     if (timed) HIPCHK(ctx, hipEventRecord(ev[0], st));
-    if (b->n_groups)
-        hipLaunchKernelGGL(k_bounds, dim3(b->n_groups), dim3(128), 0, st, b->d_groups, b->d_terms, b->d_segs, b->d_bounds, b->tile_docs);
+    if (b->n_bgroups)
+        hipLaunchKernelGGL(k_bounds, dim3(b->n_bgroups), dim3(128), 0, st, b->d_groups, b->d_terms, b->d_segs, b->d_bounds, b->tile_docs);
     if (timed) HIPCHK(ctx, hipEventRecord(ev[1], st));
     Hit* sh = b->direct ? b->o_hits : b->d_part_hits;
     uint32_t* sn = b->direct ? b->o_nhits : b->d_part_nhits;
     uint64_t* sf = b->direct ? b->o_found : b->d_part_found;
-    if (b->n_items) {
-        switch (b->variant) {
-            case 1: launch_score<1024, 12, 4>(and_mode, b->n_items, st, b->d_items, b->d_terms, b->d_segs, b->d_bounds, sh, sn, sf, b->K); break;
-            case 3: launch_score<256, 16, 4>(and_mode, b->n_items, st, b->d_items, b->d_terms, b->d_segs, b->d_bounds, sh, sn, sf, b->K); break;
-            case 4: launch_score<512, 16, 8>(and_mode, b->n_items, st, b->d_items, b->d_terms, b->d_segs, b->d_bounds, sh, sn, sf, b->K); break;
-            default: launch_score<512, 12, 4>(and_mode, b->n_items, st, b->d_items, b->d_terms, b->d_segs, b->d_bounds, sh, sn, sf, b->K); break;
+    if (b->n_witems) {
+        switch (b->hb) {
+            case 256: launch_wscore<256>(and_mode, b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K); break;
+            case 1024: launch_wscore<1024>(and_mode, b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K); break;
+            default: launch_wscore<512>(and_mode, b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K); break;
         }
+    }
+    if (b->n_items) {
+        const VariantDesc vd = kVariants[b->variant];
+        if (vd.nt == 1024) launch_score<1024, 12, 4>(and_mode, b->n_items, st, b->d_items, b->d_terms, b->d_segs, b->d_bounds, sh, sn, sf, b->K);
+        else if (vd.nt == 256) launch_score<256, 16, 4>(and_mode, b->n_items, st, b->d_items, b->d_terms, b->d_segs, b->d_bounds, sh, sn, sf, b->K);
+        else if (vd.spt == 16) launch_score<512, 16, 8>(and_mode, b->n_items, st, b->d_items, b->d_terms, b->d_segs, b->d_bounds, sh, sn, sf, b->K);
+        else launch_score<512, 12, 4>(and_mode, b->n_items, st, b->d_items, b->d_terms, b->d_segs, b->d_bounds, sh, sn, sf, b->K);
     }
     if (timed) HIPCHK(ctx, hipEventRecord(ev[2], st));
     if (!b->direct && b->Q)
@@ -530,7 +606,7 @@ extern "C" int ns_batch_get_info(ns_batch* b, ns_batch_info* info) {
     info->postings = b->postings;
     info->algo_bytes = b->postings * 8;
     info->n_queries = b->Q;
-    info->n_items = b->n_items;
+    info->n_items = b->n_items + b->n_witems;
     info->n_term_refs = b->n_terms;
     info->tile_docs = b->tile_docs;
     info->k = b->K;

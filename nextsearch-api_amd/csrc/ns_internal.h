@@ -13,6 +13,7 @@ static constexpr uint32_t kSentinelBits = 0x80000000u;
 
 struct DevSeg {
     const uint2* postings;   // {docId, tf} pairs, all inverted files of the segment back to back
+    const float* pnorm;      // per POSTING: norm[docId] (streams next to the posting; no dependent gather)
     const float* norm;       // per doc: k1*((1-b) + b*(doc_len/avgdl))   (src/api_engine.cpp:478)
     uint64_t     n_postings;
     uint32_t     n_docs;
@@ -40,6 +41,19 @@ struct DevItem {
     uint32_t tile_end;
     uint32_t out_slot;     // row of the (partial or final) result arrays
     uint32_t pad;
+};
+
+// Work item of the wave-private kernel k_wscore: one WAVE scores one (query, segment) term group
+// (<= 64 terms) over the doc range [doc_lo, doc_hi).
+struct DevWItem {
+    uint32_t query;
+    uint32_t seg;
+    uint32_t term_begin;   // into DevTerm[]
+    uint32_t term_count;   // 1..64
+    uint32_t doc_lo;
+    uint32_t doc_hi;
+    uint32_t out_slot;
+    uint32_t whole;        // 1: range covers the whole segment (no start/end searches needed)
 };
 
 // Term group == the (query, segment) unit the boundary prepass works on.

@@ -1,0 +1,321 @@
+// k_wscore — the wave-private scoring kernel (default path for term groups of <= 64 terms).
+//
+// One WAVE (64 lanes) scores one work item = one (query, segment) term group over a doc range,
+// with no workgroup barrier anywhere: every wave of the chip is an independent worker, so posting
+// loads of ~20-28 waves per CU overlap and nothing waits on a slower wave.
+//
+// Per wave, in LDS: an HB-entry accumulator table (fp32 value + docId key), a 256-entry candidate
+// buffer (64-bit sort keys).  The wave walks its posting lists in BATCHES of <= HB/2 postings:
+//   1. lane t owns term t: cursor, list end, idf, weight.  Window sizes w_t are proportional to the
+//      remaining list lengths, so all windows span about the same doc range.
+//   2. one probe per term of the last docId in its window; hi = min over terms: every posting with
+//      docId <= hi of every term lies inside its window (lists are docId-ascending).
+//   3. term by term (query-term order == fp32 accumulation order of src/api_engine.cpp:480), chunk
+//      by chunk of 64: coalesced loads of {docId,tf} and of the per-posting norm (no dependent
+//      gather), BM25 term score in the reference's operation order, ds_add_f32 into the table —
+//      direct-mapped when the batch spans <= HB docs, else open-addressing hash keyed by docId.
+//   4. read the table back from registers: `found` (:495), candidates above the running K-th best
+//      (:485-492) into the candidate buffer (bitonic-sorted by the wave when it fills), reset.
+// The doc ranges of successive batches ascend, which is what makes "score > theta" an exact filter
+// under the canonical tie order (score desc, docId asc).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ns_internal.h"
+
+namespace ns {
+
+__device__ __forceinline__ void wave_sync() {
+    // LDS operations of one wave execute in issue order; this only stops the compiler from moving
+    // LDS accesses across a phase boundary.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = min(v, (uint32_t)__shfl_xor(v, d, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// in-LDS bitonic sort (descending) of a[0..P), P a power of two, by ONE wave
+__device__ __forceinline__ void wave_bitonic_desc(uint64_t* a, uint32_t P, int lane) {
+    for (uint32_t k = 2; k <= P; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t q = lane; q < (P >> 1); q += 64) {
+                uint32_t i = ((q & ~(j - 1)) << 1) | (q & (j - 1));
+                uint32_t p = i | j;
+                uint64_t x = a[i], y = a[p];
+                bool desc = (i & k) == 0;
+                if (desc ? (x < y) : (x > y)) { a[i] = y; a[p] = x; }
+            }
+            wave_sync();
+        }
+    }
+}
+
+// Sort the wave's candidates, keep the best min(n, K), raise theta to the K-th best.
+// Returns (theta bits << 32) | new n  (by value: a reference would push theta to scratch).
+__device__ __noinline__ uint64_t wave_shrink_packed(uint64_t* cand, uint32_t n, uint32_t theta_bits, uint32_t K, int lane) {
+    uint32_t P = 2;
+    while (P < n) P <<= 1;
+    for (uint32_t i = n + lane; i < P; i += 64) cand[i] = 0;   // padding sorts last
+    wave_sync();
+    wave_bitonic_desc(cand, P, lane);
+    if (n >= K) {
+        theta_bits = __float_as_uint(unorder_bits((uint32_t)(cand[K - 1] >> 32)));   // same address in all lanes: broadcast
+        n = K;
+    }
+    return ((uint64_t)theta_bits << 32) | n;
+}
+__device__ __forceinline__ uint32_t wave_shrink(uint64_t* cand, uint32_t n, float& theta, uint32_t K, int lane) {
+    uint64_t r = wave_shrink_packed(cand, n, __float_as_uint(theta), K, lane);
+    theta = __uint_as_float((uint32_t)(r >> 32));
+    return (uint32_t)r;
+}
+
+__device__ __forceinline__ uint32_t list_lower_bound(const uint2* lst, uint32_t count, uint32_t doc) {
+    uint32_t lo = 0, hi = count;
+    while (lo < hi) {
+        uint32_t mid = lo + ((hi - lo) >> 1);
+        if (lst[mid].x < doc) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+template <int HB, bool AND>
+__global__ void __launch_bounds__(256) k_wscore(const DevWItem* __restrict__ items, uint32_t n_items,
+                                                const DevTerm* __restrict__ terms, const DevSeg* __restrict__ segs,
+                                                Hit* __restrict__ out_hits, uint32_t* __restrict__ out_nhits,
+                                                uint64_t* __restrict__ out_found, uint32_t K) {
+    constexpr int WPB = 4;                 // independent waves per workgroup
+    constexpr int CB = 256;                // candidate buffer entries (>= NS_MAX_K + 64, power of two)
+    constexpr int BUDGET = HB / 2;         // postings per batch (hash load factor <= 1/2)
+    constexpr int NG = HB / 256;           // float4 groups per lane
+    constexpr int LOG2HB = (HB == 256) ? 8 : (HB == 512 ? 9 : (HB == 1024 ? 10 : 11));
+    constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+    static_assert(HB == 256 || HB == 512 || HB == 1024 || HB == 2048, "HB must be 256..2048");
+
+    __shared__ __attribute__((aligned(16))) float s_vals[WPB][HB];
+    __shared__ __attribute__((aligned(16))) uint32_t s_keys[WPB][HB];
+    __shared__ __attribute__((aligned(16))) uint32_t s_mcnt[WPB][AND ? HB / 4 : 4];
+    __shared__ uint64_t s_cand[WPB][CB];
+
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const uint32_t item_idx = blockIdx.x * WPB + wave;
+    if (item_idx >= n_items) return;   // whole wave leaves; there is no workgroup barrier in this kernel
+
+    float* vals = s_vals[wave];
+    uint32_t* keys = s_keys[wave];
+    uint32_t* mcnt = s_mcnt[wave];
+    uint64_t* cand = s_cand[wave];
+
+    const DevWItem it = items[item_idx];
+    const DevSeg seg = segs[it.seg];
+    const uint32_t T = it.term_count;
+    const uint2* __restrict__ postings = seg.postings;
+    const float* __restrict__ pnorm = seg.pnorm;
+
+    const float4 sent4 = make_float4(__uint_as_float(kSentinelBits), __uint_as_float(kSentinelBits),
+                                     __uint_as_float(kSentinelBits), __uint_as_float(kSentinelBits));
+    const uint4 empty4 = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+    float4* v4 = reinterpret_cast<float4*>(vals);
+    uint4* k4 = reinterpret_cast<uint4*>(keys);
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        v4[g * 64 + lane] = sent4;
+        k4[g * 64 + lane] = empty4;
+        if (AND) mcnt[g * 64 + lane] = 0;
+    }
+
+    // ---- lane t owns term t ----
+    uint32_t base_lo = 0, base_hi = 0, cur = 0, end = 0, idf_bits = 0, wq_bits = 0;
+    if ((uint32_t)lane < T) {
+        const DevTerm tm = terms[it.term_begin + lane];
+        base_lo = (uint32_t)tm.list_off;
+        base_hi = (uint32_t)(tm.list_off >> 32);
+        idf_bits = __float_as_uint(tm.idf);
+        wq_bits = __float_as_uint(tm.weight);
+        end = tm.count;
+        if (!it.whole) {
+            const uint2* lst = postings + tm.list_off;
+            cur = list_lower_bound(lst, tm.count, it.doc_lo);
+            end = list_lower_bound(lst, tm.count, it.doc_hi);
+            if (end < cur) end = cur;
+        }
+    }
+
+    uint32_t lo = it.doc_lo;
+    const uint32_t last_doc = it.doc_hi - 1;   // host guarantees doc_hi > doc_lo and doc_hi <= n_docs
+    float theta = -__builtin_inff();
+    uint32_t ncand = 0;
+    uint32_t found = 0;
+    wave_sync();
+
+    for (;;) {
+        const uint32_t rem = ((uint32_t)lane < T) ? (end - cur) : 0u;
+        const unsigned long long act = __ballot(rem > 0);
+        if (act == 0ull) break;
+        const uint32_t nact = (uint32_t)__popcll(act);
+        // window sizes proportional to what is left of each list: Sum(w) <= BUDGET (+ fp slop << HB/2)
+        const float R = wave_sum_f32((float)rem);
+        const float scale = (float)(BUDGET - (int)nact) / R;
+        uint32_t w = 0;
+        if (rem > 0) {
+            w = 1u + (uint32_t)((float)rem * scale);
+            if (w > rem) w = rem;
+        }
+        // last docId inside each window that does not reach its list's end
+        uint32_t e = 0xFFFFFFFFu;
+        if (w < rem) e = postings[(((uint64_t)base_hi << 32) | base_lo) + cur + w - 1].x;
+        uint32_t hi = wave_min_u32(e);
+        if (hi > last_doc) hi = last_doc;
+        const bool direct = (hi >= lo) && ((hi - lo) < (uint32_t)HB);   // uniform
+
+        uint32_t batch_consumed = 0;
+        for (uint32_t t = 0; t < T; t++) {
+            const uint32_t wt = rdlane(w, t);
+            if (wt == 0) continue;
+            const uint64_t b = (((uint64_t)rdlane(base_hi, t) << 32) | rdlane(base_lo, t)) + rdlane(cur, t);
+            const float idf = __uint_as_float(rdlane(idf_bits, t));
+            const float wq = __uint_as_float(rdlane(wq_bits, t));
+            const uint2* __restrict__ pl = postings + b;
+            const float* __restrict__ pn = pnorm + b;
+            uint32_t consumed = 0;
+            for (uint32_t c = 0; c < wt; c += 64) {
+                const uint32_t i = c + lane;
+                const bool inb = i < wt;
+                uint2 p = make_uint2(0xFFFFFFFFu, 0u);
+                float nr = 1.0f;
+                if (inb) { p = pl[i]; nr = pn[i]; }
+                const bool take = inb && (p.x <= hi);
+                const unsigned long long tmask = __ballot(take);
+                consumed += (uint32_t)__popcll(tmask);
+                const uint32_t d = p.x - lo;
+                // p.x < lo only for corrupt (unsorted) lists: such postings are consumed, not scored
+                const bool ok = take && (p.x >= lo);
+                // src/api_engine.cpp:477-480, operation for operation (k1 + 1.0f == 0x400CCCCD)
+                const float tf = (float)p.y;
+                const float denom = tf + nr;
+                const float s = (idf * (tf * (1.2f + 1.0f))) / denom;
+                const float x = wq * s;
+                if (ok) {
+                    uint32_t slot;
+                    if (direct) {
+                        slot = d;
+                    } else {
+                        slot = (p.x * 2654435761u) >> (32 - LOG2HB);
+                        for (int probe = 0; probe < HB; probe++) {
+                            const uint32_t old = atomicCAS(&keys[slot], EMPTY, p.x);
+                            if (old == EMPTY || old == p.x) break;
+                            slot = (slot + 1) & (HB - 1);
+                        }
+                    }
+                    atomicAdd(&vals[slot], x);   // ds_add_f32
+                    if (AND) atomicAdd(&mcnt[slot >> 2], 1u << ((slot & 3) * 8));
+                }
+                if (tmask != __ballot(inb)) break;   // docIds ascend: nothing further in this window is <= hi
+            }
+            if ((uint32_t)lane == t) cur += consumed;
+            batch_consumed += consumed;
+        }
+        if (batch_consumed == 0) cur += w;   // only with corrupt lists (docIds beyond the range): skip the windows
+
+        // ---- read the table back: found, candidates, reset ----
+        wave_sync();
+        bool ge_mode = false;   // after a shrink INSIDE this batch, ties with theta may still win on docId
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            const float4 q = v4[g * 64 + lane];
+            uint4 kk = empty4;
+            if (!direct) kk = k4[g * 64 + lane];
+            uint32_t cw = 0;
+            if (AND) cw = mcnt[g * 64 + lane];
+            const float vv[4] = {q.x, q.y, q.z, q.w};
+            const uint32_t kd[4] = {kk.x, kk.y, kk.z, kk.w};
+            bool any = false;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                bool touched = __float_as_uint(vv[c]) != kSentinelBits;
+                any = any || touched || (kd[c] != EMPTY);
+                if (AND) touched = touched && (((cw >> (8 * c)) & 0xFFu) == T);
+                found += (uint32_t)__popcll(__ballot(touched));
+                bool qf = touched && (ge_mode ? (vv[c] >= theta) : (vv[c] > theta));
+                unsigned long long mask = __ballot(qf);
+                if (mask != 0ull) {
+                    uint32_t n = (uint32_t)__popcll(mask);
+                    if (ncand + n > (uint32_t)CB) {
+                        ncand = wave_shrink(cand, ncand, theta, K, lane);
+                        ge_mode = true;
+                        qf = touched && (vv[c] >= theta);
+                        mask = __ballot(qf);
+                        n = (uint32_t)__popcll(mask);
+                    }
+                    if (qf) {
+                        const uint32_t doc = direct ? (lo + (uint32_t)((g * 64 + lane) * 4 + c)) : kd[c];
+                        cand[ncand + lanes_below(mask)] = make_key(vv[c], doc);
+                    }
+                    ncand += n;
+                }
+            }
+            if (any) {
+                v4[g * 64 + lane] = sent4;
+                if (!direct) k4[g * 64 + lane] = empty4;
+                if (AND) mcnt[g * 64 + lane] = 0;
+            }
+        }
+        wave_sync();
+        if (ncand > (uint32_t)(CB / 2)) ncand = wave_shrink(cand, ncand, theta, K, lane);
+        if (hi >= last_doc) break;
+        lo = hi + 1;
+    }
+
+    // ---- this item's top-K ----
+    wave_sync();
+    ncand = wave_shrink(cand, ncand, theta, K, lane);
+    const uint32_t n = min(ncand, K);
+    Hit* oh = out_hits + (uint64_t)it.out_slot * K;
+    for (uint32_t i = lane; i < K; i += 64) {
+        Hit h;
+        if (i < n) {
+            const uint64_t key = cand[i];
+            h.score = unorder_bits((uint32_t)(key >> 32));
+            h.seg = it.seg;
+            h.doc = 0xFFFFFFFFu - (uint32_t)key;
+        } else {
+            h.score = -__builtin_inff();
+            h.seg = 0xFFFFFFFFu;
+            h.doc = 0xFFFFFFFFu;
+        }
+        oh[i] = h;
+    }
+    if (lane == 0) {
+        out_nhits[it.out_slot] = n;
+        out_found[it.out_slot] = (uint64_t)found;
+    }
+}
+
+// per-posting norm, built once at upload: pnorm[i] = norm[postings[i].docId]
+__global__ void k_pnorm(const uint2* __restrict__ postings, const float* __restrict__ norm, float* __restrict__ pnorm,
+                        uint64_t n_postings, uint32_t n_docs) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n_postings; i += stride) {
+        uint32_t d = postings[i].x;
+        pnorm[i] = d < n_docs ? norm[d] : 1.0f;
+    }
+}
+
+}  // namespace ns

@@ -94,7 +94,7 @@ def hip_lib():
         L.ns_batch_get_info.argtypes = [vp, C.POINTER(NsBatchInfo)]
         L.ns_batch_destroy.argtypes = [vp]
         L.ns_batch_destroy.restype = None
-        L.ns_set_tuning.argtypes = [vp, u32, u32]
+        L.ns_set_tuning.argtypes = [vp, u32, u32, u32]
         _hip = L
     return _hip
 
@@ -311,8 +311,8 @@ class Engine:
             raise RuntimeError(f"prepare failed: {self.error()}")
         return Batch(b, len(queries), clamp_k(k))
 
-    def set_tuning(self, variant=0, min_items=0):
-        rc = hip_lib().ns_set_tuning(self.ctx, variant, min_items)
+    def set_tuning(self, variant=0, min_items=0, split_postings=0):
+        rc = hip_lib().ns_set_tuning(self.ctx, variant, min_items, split_postings)
         if rc != NS_OK:
             raise RuntimeError(hip_lib().ns_last_error(self.ctx).decode())
 

@@ -70,29 +70,40 @@ def test_gpu_equals_oracle_and_reference_golden(name, engines):
             assert [int(b) for b in gh[qi, : gn[qi]]["score"].view(np.uint32)] == [h[2] for h in ref["hits"]]
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7])
 def test_kernel_variants_agree(variant, engines):
+    """Wave-private kernel (5/6/7: 256/512/1024-entry tables) and workgroup-tile kernel (1..4)."""
     g, eng, ora = engines("mid1")
     queries = g["queries"]
-    eng.set_tuning(variant, 0)
+    eng.set_tuning(variant, 0, 0)
     try:
         for k in (1, 10, 100):
             assert_same(eng.search_batch(queries, k), ora.search_batch(queries, k), queries, f"variant {variant} k={k}")
+        assert_same(eng.search_batch(queries, 10, nsbind.NS_FLAG_AND), ora.search_batch(queries, 10, orc.FLAG_AND), queries,
+                    f"variant {variant} AND")
     finally:
-        eng.set_tuning(0, 0)
+        eng.set_tuning(0, 0, 0)
 
 
-@pytest.mark.parametrize("min_items", [1, 64, 4096])
-def test_doc_range_splitting_is_invisible(min_items, engines):
-    """Small batches are split into several doc-tile ranges per query and merged on the device."""
+@pytest.mark.parametrize("variant,min_items,split", [(3, 1, 0), (3, 64, 0), (3, 4096, 0), (0, 1, 1 << 30), (0, 1, 500),
+                                                      (0, 4096, 0), (5, 1, 64), (7, 100000, 1000)])
+def test_doc_range_splitting_is_invisible(variant, min_items, split, engines):
+    """Queries are split into doc ranges (by posting budget, and to fill the chip for small batches)
+    and re-joined on the device by k_merge; the result must not depend on the split."""
     g, eng, ora = engines("mid1")
-    queries = g["queries"][:12]
-    eng.set_tuning(3, min_items)   # 4096-doc tiles -> 5 tiles over 20k docs
+    queries = g["queries"][:20]
+    eng.set_tuning(variant, min_items, split)
     try:
-        assert_same(eng.search_batch(queries, 10), ora.search_batch(queries, 10), queries, f"min_items={min_items}")
+        assert_same(eng.search_batch(queries, 10), ora.search_batch(queries, 10), queries, f"v{variant} min_items={min_items} split={split}")
         assert_same(eng.search_batch(queries[:1], 100), ora.search_batch(queries[:1], 100), queries[:1], "single query")
+        g8, eng8, ora8 = engines("multi8")
+        eng8.set_tuning(variant, min_items, split)
+        try:
+            assert_same(eng8.search_batch(queries, 100), ora8.search_batch(queries, 100), queries, "multi8 split")
+        finally:
+            eng8.set_tuning(0, 0, 0)
     finally:
-        eng.set_tuning(0, 0)
+        eng.set_tuning(0, 0, 0)
 
 
 def test_and_extension_matches_derived_oracle(engines):
@@ -247,6 +258,7 @@ def test_staged_batch_with_bound_torch_outputs(engines):
     d_nhits = torch.zeros(Q, dtype=torch.int32, device="cuda")
     d_found = torch.zeros(Q, dtype=torch.int64, device="cuda")
     b.bind_outputs(d_hits.data_ptr(), d_nhits.data_ptr(), d_found.data_ptr())
+    torch.cuda.synchronize()   # the ctx runs on its own non-blocking stream: finish torch's fills first
     b.run(timed=True)
     b.sync()
     info = b.info()
