@@ -94,6 +94,30 @@ __device__ __forceinline__ uint32_t list_lower_bound(const uint2* lst, uint32_t 
     return lo;
 }
 
+// DPP wave reductions (gfx9 row_shr / row_bcast forms): 6 VALU instructions, no LDS round trips.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t old, uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROWMASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_min_dpp(uint32_t v) {
+    v = min(v, dpp_mov<0x111, 0xf>(0xFFFFFFFFu, v));   // row_shr:1
+    v = min(v, dpp_mov<0x112, 0xf>(0xFFFFFFFFu, v));   // row_shr:2
+    v = min(v, dpp_mov<0x114, 0xf>(0xFFFFFFFFu, v));   // row_shr:4
+    v = min(v, dpp_mov<0x118, 0xf>(0xFFFFFFFFu, v));   // row_shr:8
+    v = min(v, dpp_mov<0x142, 0xa>(0xFFFFFFFFu, v));   // row_bcast:15
+    v = min(v, dpp_mov<0x143, 0xc>(0xFFFFFFFFu, v));   // row_bcast:31
+    return rdlane(v, 63);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
+    v += dpp_mov<0x111, 0xf>(0u, v);
+    v += dpp_mov<0x112, 0xf>(0u, v);
+    v += dpp_mov<0x114, 0xf>(0u, v);
+    v += dpp_mov<0x118, 0xf>(0u, v);
+    v += dpp_mov<0x142, 0xa>(0u, v);
+    v += dpp_mov<0x143, 0xc>(0u, v);
+    return v;
+}
+
 template <int HB, bool AND>
 __global__ void __launch_bounds__(256) k_wscore(const DevWItem* __restrict__ items, uint32_t n_items,
                                                 const DevTerm* __restrict__ terms, const DevSeg* __restrict__ segs,
@@ -102,6 +126,7 @@ __global__ void __launch_bounds__(256) k_wscore(const DevWItem* __restrict__ ite
     constexpr int WPB = 4;                 // independent waves per workgroup
     constexpr int CB = 256;                // candidate buffer entries (>= NS_MAX_K + 64, power of two)
     constexpr int BUDGET = HB / 2;         // postings per batch (hash load factor <= 1/2)
+    constexpr int E = BUDGET / 64;         // postings per lane per batch
     constexpr int NG = HB / 256;           // float4 groups per lane
     constexpr int LOG2HB = (HB == 256) ? 8 : (HB == 512 ? 9 : (HB == 1024 ? 10 : 11));
     constexpr uint32_t EMPTY = 0xFFFFFFFFu;
@@ -111,6 +136,8 @@ __global__ void __launch_bounds__(256) k_wscore(const DevWItem* __restrict__ ite
     __shared__ __attribute__((aligned(16))) uint32_t s_keys[WPB][HB];
     __shared__ __attribute__((aligned(16))) uint32_t s_mcnt[WPB][AND ? HB / 4 : 4];
     __shared__ uint64_t s_cand[WPB][CB];
+    __shared__ __attribute__((aligned(16))) uint4 s_tab[WPB][64];   // per term: {posting address base lo/hi, idf, qweight}
+    __shared__ uint32_t s_incl[WPB][64];                             // inclusive prefix of window sizes (T > 8 lookups)
 
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
@@ -121,6 +148,8 @@ __global__ void __launch_bounds__(256) k_wscore(const DevWItem* __restrict__ ite
     uint32_t* keys = s_keys[wave];
     uint32_t* mcnt = s_mcnt[wave];
     uint64_t* cand = s_cand[wave];
+    uint4* tab = s_tab[wave];
+    uint32_t* inclv = s_incl[wave];
 
     const DevWItem it = items[item_idx];
     const DevSeg seg = segs[it.seg];
@@ -141,11 +170,11 @@ __global__ void __launch_bounds__(256) k_wscore(const DevWItem* __restrict__ ite
     }
 
     // ---- lane t owns term t ----
-    uint32_t base_lo = 0, base_hi = 0, cur = 0, end = 0, idf_bits = 0, wq_bits = 0;
+    uint64_t base = 0;
+    uint32_t cur = 0, end = 0, idf_bits = 0, wq_bits = 0;
     if ((uint32_t)lane < T) {
         const DevTerm tm = terms[it.term_begin + lane];
-        base_lo = (uint32_t)tm.list_off;
-        base_hi = (uint32_t)(tm.list_off >> 32);
+        base = tm.list_off;
         idf_bits = __float_as_uint(tm.idf);
         wq_bits = __float_as_uint(tm.weight);
         end = tm.count;
@@ -156,82 +185,152 @@ __global__ void __launch_bounds__(256) k_wscore(const DevWItem* __restrict__ ite
             if (end < cur) end = cur;
         }
     }
+    // postings still to be consumed by this item (scalar, maintained incrementally)
+    uint64_t R = 0;
+    {
+        uint32_t r32 = ((uint32_t)lane < T) ? (end - cur) : 0u;
+        for (uint32_t t = 0; t < T; t++) R += rdlane(r32, t);
+    }
 
     uint32_t lo = it.doc_lo;
     const uint32_t last_doc = it.doc_hi - 1;   // host guarantees doc_hi > doc_lo and doc_hi <= n_docs
     float theta = -__builtin_inff();
     uint32_t ncand = 0;
     uint32_t found = 0;
-    wave_sync();
 
-    for (;;) {
+    // window sizes of the first batch + the probe of each window's last docId
+    uint32_t w = 0, e = 0xFFFFFFFFu;
+    auto plan_windows = [&]() {
         const uint32_t rem = ((uint32_t)lane < T) ? (end - cur) : 0u;
-        const unsigned long long act = __ballot(rem > 0);
-        if (act == 0ull) break;
-        const uint32_t nact = (uint32_t)__popcll(act);
-        // window sizes proportional to what is left of each list: Sum(w) <= BUDGET (+ fp slop << HB/2)
-        const float R = wave_sum_f32((float)rem);
-        const float scale = (float)(BUDGET - (int)nact) / R;
-        uint32_t w = 0;
+        const uint32_t nact = (uint32_t)__popcll(__ballot(rem > 0));
+        // proportional to what is left of each list: all windows span about the same doc range;
+        // Sum(w) <= nact + (BUDGET - nact) (+ fp slop, far below the table's spare half)
+        const float scale = (float)(BUDGET - (int)nact) / (float)R;
+        w = 0;
+        e = 0xFFFFFFFFu;
         if (rem > 0) {
             w = 1u + (uint32_t)((float)rem * scale);
             if (w > rem) w = rem;
+            if (w < rem) e = postings[base + cur + w - 1].x;   // last docId inside a window that stops short of its list's end
         }
-        // last docId inside each window that does not reach its list's end
-        uint32_t e = 0xFFFFFFFFu;
-        if (w < rem) e = postings[(((uint64_t)base_hi << 32) | base_lo) + cur + w - 1].x;
-        uint32_t hi = wave_min_u32(e);
+    };
+    if (R > 0) plan_windows();
+    wave_sync();
+
+    while (R > 0) {
+        // ---- batch geometry ----
+        const uint32_t incl = wave_incl_scan_dpp(w);
+        const uint32_t total = rdlane(incl, 63);
+        if ((uint32_t)lane < T) {
+            const uint64_t ab = base + cur - (uint64_t)(incl - w);   // element p of the flat batch lives at ab + p
+            tab[lane] = make_uint4((uint32_t)ab, (uint32_t)(ab >> 32), idf_bits, wq_bits);
+        }
+        if (T > 8) inclv[lane] = incl;
+        uint32_t hi = wave_min_dpp(e);   // every posting with docId <= hi of every term is inside its window
         if (hi > last_doc) hi = last_doc;
         const bool direct = (hi >= lo) && ((hi - lo) < (uint32_t)HB);   // uniform
+        wave_sync();
 
+        // ---- flat, coalesced loads of the whole batch (all in flight together) ----
+        uint32_t tj[E];
+        bool inb[E];
+#pragma unroll
+        for (int j = 0; j < E; j++) { tj[j] = 0; inb[j] = (uint32_t)(j * 64 + lane) < total; }
+        if (T <= 8) {
+            for (uint32_t t = 0; t + 1 < T; t++) {
+                const uint32_t sp = rdlane(incl, t);
+#pragma unroll
+                for (int j = 0; j < E; j++) tj[j] += ((uint32_t)(j * 64 + lane) >= sp) ? 1u : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < E; j++) {
+                const uint32_t p = (uint32_t)(j * 64 + lane);
+                uint32_t a = 0, b = T - 1;   // smallest t with incl[t] > p
+                while (a < b) {
+                    const uint32_t m = (a + b) >> 1;
+                    if (inclv[m] > p) b = m; else a = m + 1;
+                }
+                tj[j] = a;
+            }
+        }
+        uint2 pst[E];
+        float nrm[E], idfv[E], wqv[E];
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            const uint4 ent = tab[tj[j]];
+            const uint64_t addr = (((uint64_t)ent.y << 32) | ent.x) + (uint32_t)(j * 64 + lane);
+            idfv[j] = __uint_as_float(ent.z);
+            wqv[j] = __uint_as_float(ent.w);
+            pst[j] = make_uint2(0xFFFFFFFFu, 0u);
+            nrm[j] = 1.0f;
+            if (inb[j]) { pst[j] = postings[addr]; nrm[j] = pnorm[addr]; }
+        }
+
+        // ---- how much of each window is consumed (docId <= hi), cursor update ----
+        bool take[E];
+        uint32_t tmin[E], tmax[E];
         uint32_t batch_consumed = 0;
-        for (uint32_t t = 0; t < T; t++) {
-            const uint32_t wt = rdlane(w, t);
-            if (wt == 0) continue;
-            const uint64_t b = (((uint64_t)rdlane(base_hi, t) << 32) | rdlane(base_lo, t)) + rdlane(cur, t);
-            const float idf = __uint_as_float(rdlane(idf_bits, t));
-            const float wq = __uint_as_float(rdlane(wq_bits, t));
-            const uint2* __restrict__ pl = postings + b;
-            const float* __restrict__ pn = pnorm + b;
-            uint32_t consumed = 0;
-            for (uint32_t c = 0; c < wt; c += 64) {
-                const uint32_t i = c + lane;
-                const bool inb = i < wt;
-                uint2 p = make_uint2(0xFFFFFFFFu, 0u);
-                float nr = 1.0f;
-                if (inb) { p = pl[i]; nr = pn[i]; }
-                const bool take = inb && (p.x <= hi);
-                const unsigned long long tmask = __ballot(take);
-                consumed += (uint32_t)__popcll(tmask);
-                const uint32_t d = p.x - lo;
-                // p.x < lo only for corrupt (unsorted) lists: such postings are consumed, not scored
-                const bool ok = take && (p.x >= lo);
-                // src/api_engine.cpp:477-480, operation for operation (k1 + 1.0f == 0x400CCCCD)
-                const float tf = (float)p.y;
-                const float denom = tf + nr;
-                const float s = (idf * (tf * (1.2f + 1.0f))) / denom;
-                const float x = wq * s;
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            take[j] = inb[j] && (pst[j].x <= hi);
+            tmin[j] = 1; tmax[j] = 0;
+            if ((uint32_t)(j * 64) < total) {   // uniform
+                const uint32_t last = min(63u, total - 1u - (uint32_t)(j * 64));
+                tmin[j] = rdlane(tj[j], 0);
+                tmax[j] = rdlane(tj[j], last);
+                for (uint32_t tt = tmin[j]; tt <= tmax[j]; tt++) {
+                    const uint32_t c = (uint32_t)__popcll(__ballot(take[j] && tj[j] == tt));
+                    if ((uint32_t)lane == tt) cur += c;
+                    batch_consumed += c;
+                }
+            }
+        }
+        const uint32_t w_done = w;
+        if (batch_consumed == 0) {   // only with corrupt lists (docIds beyond the range): skip the windows
+            cur += w_done;
+            batch_consumed = total;
+        }
+        R = (R > batch_consumed) ? (R - batch_consumed) : 0;
+        // plan the next batch now: its docId probes fly while this batch is scored and read back
+        if (R > 0) plan_windows();
+
+        // ---- BM25 term scores, table insert, ordered accumulation ----
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            if ((uint32_t)(j * 64) >= total) continue;   // uniform
+            // p.x < lo only for corrupt (unsorted) lists: such postings are consumed, not scored
+            const bool ok = take[j] && (pst[j].x >= lo);
+            // src/api_engine.cpp:477-480, operation for operation (k1 + 1.0f == 0x400CCCCD)
+            const float tf = (float)pst[j].y;
+            const float denom = tf + nrm[j];
+            const float sc = (idfv[j] * (tf * (1.2f + 1.0f))) / denom;
+            const float x = wqv[j] * sc;
+            uint32_t slot = pst[j].x - lo;
+            if (!direct && ok) {
+                slot = (pst[j].x * 2654435761u) >> (32 - LOG2HB);
+                for (int probe = 0; probe < HB; probe++) {
+                    const uint32_t old = atomicCAS(&keys[slot], EMPTY, pst[j].x);
+                    if (old == EMPTY || old == pst[j].x) break;
+                    slot = (slot + 1) & (HB - 1);
+                }
+            }
+            if (tmax[j] <= 1 || tmin[j] == tmax[j]) {
+                // one term, or only terms 0 and 1 (which commute exactly: (-0 + a) + b == (-0 + b) + a)
                 if (ok) {
-                    uint32_t slot;
-                    if (direct) {
-                        slot = d;
-                    } else {
-                        slot = (p.x * 2654435761u) >> (32 - LOG2HB);
-                        for (int probe = 0; probe < HB; probe++) {
-                            const uint32_t old = atomicCAS(&keys[slot], EMPTY, p.x);
-                            if (old == EMPTY || old == p.x) break;
-                            slot = (slot + 1) & (HB - 1);
-                        }
-                    }
                     atomicAdd(&vals[slot], x);   // ds_add_f32
                     if (AND) atomicAdd(&mcnt[slot >> 2], 1u << ((slot & 3) * 8));
                 }
-                if (tmask != __ballot(inb)) break;   // docIds ascend: nothing further in this window is <= hi
+            } else {
+                // several terms inside one 64-lane chunk: issue the adds term by term (query-term order)
+                for (uint32_t tt = tmin[j]; tt <= tmax[j]; tt++) {
+                    if (ok && tj[j] == tt) {
+                        atomicAdd(&vals[slot], x);
+                        if (AND) atomicAdd(&mcnt[slot >> 2], 1u << ((slot & 3) * 8));
+                    }
+                }
             }
-            if ((uint32_t)lane == t) cur += consumed;
-            batch_consumed += consumed;
         }
-        if (batch_consumed == 0) cur += w;   // only with corrupt lists (docIds beyond the range): skip the windows
 
         // ---- read the table back: found, candidates, reset ----
         wave_sync();

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the scoring kernel on synthetic query laws (diagnostic tool, GPU box only).
+
+    python tools/law_bench.py [--variant V] [--split S] [--laws A,B,...]
+
+Prints, per law: queries, postings/query, kernel ms, ns per posting-lane and algorithmic GB/s.
+"""
+import argparse
+import os
+import random
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "nextsearch-api_amd"))
+import nsbind  # noqa: E402
+import workloads  # noqa: E402
+
+T = workloads.term_name
+
+
+def laws():
+    rng = random.Random(1)
+    L = {}
+    L["r1"] = ([T(1)] * 1024, 10)
+    L["r2"] = ([T(2)] * 2048, 10)
+    L["r4"] = ([T(4)] * 4096, 10)
+    L["r8"] = ([T(8)] * 4096, 10)
+    L["r16"] = ([T(16)] * 8192, 10)
+    L["r32"] = ([T(32)] * 8192, 10)
+    L["r100"] = ([T(100 + i % 50) for i in range(16384)], 10)
+    L["r1000"] = ([T(1000 + i % 500) for i in range(16384)], 10)
+    L["r1000x3"] = ([" ".join(T(rng.randint(1000, 3000)) for _ in range(3)) for _ in range(16384)], 10)
+    L["r10000x3"] = ([" ".join(T(rng.randint(10000, 30000)) for _ in range(3)) for _ in range(16384)], 10)
+    L["r1+r1000x2"] = ([T(1) + " " + " ".join(T(rng.randint(1000, 3000)) for _ in range(2)) for _ in range(1024)], 10)
+    L["r8+r1000x2"] = ([T(8) + " " + " ".join(T(rng.randint(1000, 3000)) for _ in range(2)) for _ in range(4096)], 10)
+    L["r1r2r3r4r5"] = ([" ".join(T(r) for r in (1, 2, 3, 4, 5))] * 512, 100)
+    L["cfg5"] = (workloads.cfg5_queries(), 10)
+    L["cfg3"] = (workloads.cfg3_queries(), 100)
+    return L
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--split", type=int, default=0)
+    ap.add_argument("--laws", default="")
+    ap.add_argument("--reps", type=int, default=5)
+    args = ap.parse_args()
+    tmp = tempfile.TemporaryDirectory(prefix="ns_law_")
+    idx = os.path.join(tmp.name, "index")
+    nsbind.gen_index(idx, 1, 1_000_000, 65536, 1337, False)
+    eng = nsbind.Engine(idx, 0)
+    eng.set_tuning(args.variant, 0, args.split)
+    L = laws()
+    names = [n for n in args.laws.split(",") if n] or list(L.keys())
+    print(f"variant={args.variant} split={args.split}")
+    print(f"{'law':>14} {'Q':>6} {'post/q':>9} {'items':>7} {'kern_ms':>9} {'ns/post':>8} {'GB/s':>8} {'frac':>6}")
+    for n in names:
+        qs, k = L[n]
+        b = eng.prepare(qs, k)
+        b.run(False)
+        b.sync()
+        for _ in range(args.reps):
+            b.run(True)
+        b.sync()
+        inf = b.info()
+        ms = inf.sum_score_kernel_ms / inf.timed_runs
+        gbs = inf.algo_bytes / (ms * 1e-3) / 1e9
+        print(f"{n:>14} {len(qs):>6} {inf.postings / len(qs):>9.0f} {inf.n_items:>7} {ms:>9.3f} {ms * 1e6 / inf.postings:>8.4f} {gbs:>8.0f} {gbs / 8000:>6.3f}")
+        b.close()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
