@@ -78,10 +78,23 @@ static const VariantDesc kVariants[] = {
     {256, 512, 12, 4},    // 5: wave kernel, 256-entry tables
     {512, 512, 12, 4},    // 6: wave kernel, 512-entry tables
     {1024, 512, 12, 4},   // 7: wave kernel, 1024-entry tables
+    // diagnostic ablations of variant 0 (results are wrong by construction; never used by the product)
+    {512, 512, 12, 4},    // 8: approximate division
+    {512, 512, 12, 4},    // 9: no table adds
+    {512, 512, 12, 4},    // 10: no read-back
+    {512, 512, 12, 4},    // 11: no norm load
+    {512, 512, 12, 4},    // 12: no consumed counting
+    {512, 512, 12, 4},    // 13: 1+2+4+8+16
 };
 static constexpr uint32_t kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 static constexpr uint32_t kWaveMaxTerms = 64;
 static constexpr uint32_t kDefaultSplitPostings = 32768;
+
+template <int ABL>
+static void launch_wscore_abl(uint32_t n_items, hipStream_t st, const DevWItem* items, const DevTerm* terms,
+                              const DevSeg* segs, Hit* hits, uint32_t* nhits, uint64_t* found, uint32_t K) {
+    hipLaunchKernelGGL((k_wscore<512, false, ABL>), dim3((n_items + 3) / 4), dim3(256), 0, st, items, n_items, terms, segs, hits, nhits, found, K);
+}
 
 template <int HB>
 static void launch_wscore(bool and_mode, uint32_t n_items, hipStream_t st, const DevWItem* items, const DevTerm* terms,
@@ -173,6 +186,7 @@ extern "C" int ns_segment_upload(ns_ctx* ctx, uint32_t seg_id, uint32_t n_docs, 
     if (out) *out = nullptr;
     if (seg_id >= (1u << 20)) return fail(ctx, NS_E_INVAL, "seg_id %u too large", seg_id);
     if (nbytes % 8 != 0) return fail(ctx, NS_E_INVAL, "posting payload of %llu bytes is not a whole number of {u32,u32} pairs", (unsigned long long)nbytes);
+    if (nbytes / 8 >= (1ull << 32)) return fail(ctx, NS_E_INVAL, "segment has %llu postings; this build indexes postings with 32 bits (split the segment)", (unsigned long long)(nbytes / 8));
     if ((n_docs && !doc_len) || (nbytes && !postings)) return fail(ctx, NS_E_INVAL, "null doc_len/postings");
     if (seg_id < ctx->segs.size() && ctx->segs[seg_id]) return fail(ctx, NS_E_INVAL, "segment %u already uploaded", seg_id);
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -547,7 +561,16 @@ extern "C" int ns_batch_run(ns_batch* b, int timed) {
     Hit* sh = b->direct ? b->o_hits : b->d_part_hits;
     uint32_t* sn = b->direct ? b->o_nhits : b->d_part_nhits;
     uint64_t* sf = b->direct ? b->o_found : b->d_part_found;
-    if (b->n_witems) {
+    if (b->n_witems && b->variant >= 8) {
+        switch (b->variant) {
+            case 8: launch_wscore_abl<1>(b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K); break;
+            case 9: launch_wscore_abl<2>(b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K); break;
+            case 10: launch_wscore_abl<4>(b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K); break;
+            case 11: launch_wscore_abl<8>(b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K); break;
+            case 12: launch_wscore_abl<16>(b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K); break;
+            default: launch_wscore_abl<31>(b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K); break;
+        }
+    } else if (b->n_witems) {
         switch (b->hb) {
             case 256: launch_wscore<256>(and_mode, b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K); break;
             case 1024: launch_wscore<1024>(and_mode, b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K); break;
@@ -629,3 +652,4 @@ extern "C" int ns_search_batch(ns_ctx* ctx, const ns_query_desc* queries, const 
     ns_batch_destroy(b);
     return rc;
 }
+

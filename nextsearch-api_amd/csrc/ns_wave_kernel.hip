@@ -118,7 +118,49 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
     return v;
 }
 
+// Slow half of the read-back: some slot beats theta.  Re-reads the (not yet reset) table with rolled
+// loops so that the common path stays short.  Returns (theta bits << 32) | ncand.
 template <int HB, bool AND>
+__device__ __noinline__ uint64_t wave_collect(const float* vals, const uint32_t* keys, const uint32_t* mcnt, uint64_t* cand,
+                                              uint32_t lo, uint32_t direct, uint32_t theta_bits, uint32_t ncand, uint32_t K,
+                                              uint32_t T, int lane) {
+    constexpr int CB = 256;
+    float theta = __uint_as_float(theta_bits);
+    bool ge_mode = false;   // after a shrink INSIDE this batch, ties with theta may still win on docId
+#pragma unroll 1
+    for (int i = 0; i < HB / 64; i++) {
+        const uint32_t slot = (uint32_t)(i * 64 + lane);
+        const float v = vals[slot];
+        bool touched = __float_as_uint(v) != kSentinelBits;
+        if (AND) touched = touched && (((mcnt[slot >> 2] >> (8 * (slot & 3))) & 0xFFu) == T);
+        bool qf = touched && (ge_mode ? (v >= theta) : (v > theta));
+        unsigned long long mask = __ballot(qf);
+        if (mask == 0ull) continue;
+        uint32_t n = (uint32_t)__popcll(mask);
+        if (ncand + n > (uint32_t)CB) {
+            ncand = wave_shrink(cand, ncand, theta, K, lane);
+            ge_mode = true;
+            qf = touched && (v >= theta);
+            mask = __ballot(qf);
+            n = (uint32_t)__popcll(mask);
+        }
+        if (qf) cand[ncand + lanes_below(mask)] = make_key(v, direct ? (lo + slot) : keys[slot]);
+        ncand += n;
+    }
+    wave_sync();
+    if (ncand > (uint32_t)(CB / 2)) ncand = wave_shrink(cand, ncand, theta, K, lane);
+    return ((uint64_t)__float_as_uint(theta) << 32) | ncand;
+}
+
+typedef unsigned int nat_u2 __attribute__((ext_vector_type(2)));
+// explicit global address space: pointers loaded from a descriptor are generic to the compiler, and
+// generic (flat_*) loads also tick lgkmcnt, which would serialise them with the LDS phases
+typedef const __attribute__((address_space(1))) nat_u2* gp_u2;
+typedef const __attribute__((address_space(1))) float* gp_f32;
+
+// ABL: diagnostic ablation bits (0 in every shipped path; results are WRONG when non-zero):
+//   1 approximate division, 2 no table adds, 4 no read-back, 8 no norm load, 16 no consumed counting
+template <int HB, bool AND, int ABL = 0>
 __global__ void __launch_bounds__(256) k_wscore(const DevWItem* __restrict__ items, uint32_t n_items,
                                                 const DevTerm* __restrict__ terms, const DevSeg* __restrict__ segs,
                                                 Hit* __restrict__ out_hits, uint32_t* __restrict__ out_nhits,
@@ -136,7 +178,7 @@ __global__ void __launch_bounds__(256) k_wscore(const DevWItem* __restrict__ ite
     __shared__ __attribute__((aligned(16))) uint32_t s_keys[WPB][HB];
     __shared__ __attribute__((aligned(16))) uint32_t s_mcnt[WPB][AND ? HB / 4 : 4];
     __shared__ uint64_t s_cand[WPB][CB];
-    __shared__ __attribute__((aligned(16))) uint4 s_tab[WPB][64];   // per term: {posting address base lo/hi, idf, qweight}
+    __shared__ __attribute__((aligned(16))) uint4 s_tab[WPB][64];   // per term: {idf, qweight, first posting - excl prefix, -}
     __shared__ uint32_t s_incl[WPB][64];                             // inclusive prefix of window sizes (T > 8 lookups)
 
     const int wave = threadIdx.x >> 6;
@@ -154,8 +196,8 @@ __global__ void __launch_bounds__(256) k_wscore(const DevWItem* __restrict__ ite
     const DevWItem it = items[item_idx];
     const DevSeg seg = segs[it.seg];
     const uint32_t T = it.term_count;
-    const uint2* __restrict__ postings = seg.postings;
-    const float* __restrict__ pnorm = seg.pnorm;
+    const gp_u2 postings = (gp_u2)seg.postings;
+    const gp_f32 pnorm = (gp_f32)seg.pnorm;
 
     const float4 sent4 = make_float4(__uint_as_float(kSentinelBits), __uint_as_float(kSentinelBits),
                                      __uint_as_float(kSentinelBits), __uint_as_float(kSentinelBits));
@@ -169,17 +211,16 @@ __global__ void __launch_bounds__(256) k_wscore(const DevWItem* __restrict__ ite
         if (AND) mcnt[g * 64 + lane] = 0;
     }
 
-    // ---- lane t owns term t ----
-    uint64_t base = 0;
-    uint32_t cur = 0, end = 0, idf_bits = 0, wq_bits = 0;
+    // ---- lane t owns term t (posting indices are 32-bit: upload rejects segments of >= 2^32 postings) ----
+    uint32_t base = 0, cur = 0, end = 0, idf_bits = 0, wq_bits = 0;
     if ((uint32_t)lane < T) {
         const DevTerm tm = terms[it.term_begin + lane];
-        base = tm.list_off;
+        base = (uint32_t)tm.list_off;
         idf_bits = __float_as_uint(tm.idf);
         wq_bits = __float_as_uint(tm.weight);
         end = tm.count;
         if (!it.whole) {
-            const uint2* lst = postings + tm.list_off;
+            const uint2* lst = seg.postings + tm.list_off;
             cur = list_lower_bound(lst, tm.count, it.doc_lo);
             end = list_lower_bound(lst, tm.count, it.doc_hi);
             if (end < cur) end = cur;
@@ -188,7 +229,7 @@ __global__ void __launch_bounds__(256) k_wscore(const DevWItem* __restrict__ ite
     // postings still to be consumed by this item (scalar, maintained incrementally)
     uint64_t R = 0;
     {
-        uint32_t r32 = ((uint32_t)lane < T) ? (end - cur) : 0u;
+        const uint32_t r32 = end - cur;
         for (uint32_t t = 0; t < T; t++) R += rdlane(r32, t);
     }
 
@@ -196,117 +237,149 @@ __global__ void __launch_bounds__(256) k_wscore(const DevWItem* __restrict__ ite
     const uint32_t last_doc = it.doc_hi - 1;   // host guarantees doc_hi > doc_lo and doc_hi <= n_docs
     float theta = -__builtin_inff();
     uint32_t ncand = 0;
-    uint32_t found = 0;
+    uint32_t found_lane = 0;   // per-lane count of touched slots, reduced once at the end
 
-    // window sizes of the first batch + the probe of each window's last docId
+    // Window sizes proportional to what is left of each list (so all windows span about the same doc
+    // range; Sum(w) <= BUDGET + fp slop << the table's spare half) + the probe of each window's last
+    // docId.  Planned one batch ahead: the probe flies while the current batch is scored.
     uint32_t w = 0, e = 0xFFFFFFFFu;
-    auto plan_windows = [&]() {
-        const uint32_t rem = ((uint32_t)lane < T) ? (end - cur) : 0u;
-        const uint32_t nact = (uint32_t)__popcll(__ballot(rem > 0));
-        // proportional to what is left of each list: all windows span about the same doc range;
-        // Sum(w) <= nact + (BUDGET - nact) (+ fp slop, far below the table's spare half)
-        const float scale = (float)(BUDGET - (int)nact) / (float)R;
-        w = 0;
-        e = 0xFFFFFFFFu;
-        if (rem > 0) {
-            w = 1u + (uint32_t)((float)rem * scale);
-            if (w > rem) w = rem;
-            if (w < rem) e = postings[base + cur + w - 1].x;   // last docId inside a window that stops short of its list's end
-        }
-    };
-    if (R > 0) plan_windows();
+#define NS_PLAN_WINDOWS()                                                                          \
+    {                                                                                              \
+        const uint32_t rem_ = end - cur;                                                           \
+        const uint32_t nact_ = (uint32_t)__popcll(__ballot(rem_ > 0));                             \
+        const float scale_ = (float)(BUDGET - (int)nact_) * __builtin_amdgcn_rcpf((float)R);       \
+        uint32_t w_ = 1u + (uint32_t)((float)rem_ * scale_);                                       \
+        w_ = (w_ < rem_) ? w_ : rem_;                                                              \
+        const bool probe_ = w_ < rem_;   /* false for lanes >= T (rem_ == 0) */                    \
+        const uint32_t pi_ = probe_ ? (base + cur + w_ - 1u) : 0u;                                 \
+        const nat_u2 pv_ = postings[pi_];   /* unconditional load of a valid index: no branch */   \
+        w = w_;                                                                                    \
+        e = probe_ ? pv_.x : 0xFFFFFFFFu;                                                          \
+    }
+    if (R > 0) NS_PLAN_WINDOWS();
     wave_sync();
 
     while (R > 0) {
         // ---- batch geometry ----
         const uint32_t incl = wave_incl_scan_dpp(w);
         const uint32_t total = rdlane(incl, 63);
-        if ((uint32_t)lane < T) {
-            const uint64_t ab = base + cur - (uint64_t)(incl - w);   // element p of the flat batch lives at ab + p
-            tab[lane] = make_uint4((uint32_t)ab, (uint32_t)(ab >> 32), idf_bits, wq_bits);
-        }
+        if ((uint32_t)lane < T) tab[lane] = make_uint4(idf_bits, wq_bits, base + cur - (incl - w), base + cur);
         if (T > 8) inclv[lane] = incl;
         uint32_t hi = wave_min_dpp(e);   // every posting with docId <= hi of every term is inside its window
-        if (hi > last_doc) hi = last_doc;
+        hi = min(hi, last_doc);
         const bool direct = (hi >= lo) && ((hi - lo) < (uint32_t)HB);   // uniform
         wave_sync();
 
-        // ---- flat, coalesced loads of the whole batch (all in flight together) ----
+        // ---- flat, coalesced loads of the whole batch (all in flight together, no branches:
+        //      lanes beyond `total` re-read the batch's first posting and are masked afterwards) ----
         uint32_t tj[E];
-        bool inb[E];
 #pragma unroll
-        for (int j = 0; j < E; j++) { tj[j] = 0; inb[j] = (uint32_t)(j * 64 + lane) < total; }
-        if (T <= 8) {
-            for (uint32_t t = 0; t + 1 < T; t++) {
-                const uint32_t sp = rdlane(incl, t);
+        for (int j = 0; j < E; j++) tj[j] = 0;
+        if (T > 1) {
+            if (T <= 8) {
+                for (uint32_t t = 0; t + 1 < T; t++) {
+                    const uint32_t sp = rdlane(incl, t);
 #pragma unroll
-                for (int j = 0; j < E; j++) tj[j] += ((uint32_t)(j * 64 + lane) >= sp) ? 1u : 0u;
+                    for (int j = 0; j < E; j++) tj[j] += ((uint32_t)(j * 64 + lane) >= sp) ? 1u : 0u;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < E; j++) {
+                    const uint32_t p = min((uint32_t)(j * 64 + lane), total - 1u);
+                    uint32_t a = 0, b = T - 1;   // smallest t with incl[t] > p
+                    while (a < b) {
+                        const uint32_t m = (a + b) >> 1;
+                        if (inclv[m] > p) b = m; else a = m + 1;
+                    }
+                    tj[j] = a;
+                }
             }
-        } else {
+        }
+        nat_u2 pst[E];
+        float nrm[E];
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            const uint32_t p = (uint32_t)(j * 64 + lane);
+            const bool inb = p < total;
+            tj[j] = inb ? tj[j] : 0u;
+            const uint32_t idx = tab[tj[j]].z + (inb ? p : 0u);
+            pst[j] = postings[idx];
+            nrm[j] = (ABL & 8) ? 1.0f : pnorm[idx];
+            pst[j].x = inb ? pst[j].x : 0xFFFFFFFFu;   // docId ~0 is never <= hi
+        }
+
+        // ---- how much of each window is consumed (docId <= hi): cursor update ----
+        // docIds ascend inside a window, so "taken" is a prefix of it: the first posting of a window
+        // that is NOT taken (or nothing, if all are) marks the new cursor.  That lane is unique per
+        // term, so it publishes its posting index with a plain LDS store; no per-term ballot loops.
+        bool take[E];
+        uint32_t tmin[E], tmax[E];
+        uint32_t batch_consumed;
+        {
+            if ((uint32_t)lane < T) inclv[lane] = base + cur + w;   // default: whole window consumed
+            wave_sync();
+            unsigned long long prev_last = 1ull;   // "element before the batch" counts as taken
 #pragma unroll
             for (int j = 0; j < E; j++) {
                 const uint32_t p = (uint32_t)(j * 64 + lane);
-                uint32_t a = 0, b = T - 1;   // smallest t with incl[t] > p
-                while (a < b) {
-                    const uint32_t m = (a + b) >> 1;
-                    if (inclv[m] > p) b = m; else a = m + 1;
+                take[j] = pst[j].x <= hi;
+                tmin[j] = 0; tmax[j] = 0;
+                if (T > 1 && (uint32_t)(j * 64) < total) {   // uniform
+                    tmin[j] = rdlane(tj[j], 0);
+                    tmax[j] = rdlane(tj[j], min(63u, total - 1u - (uint32_t)(j * 64)));
                 }
-                tj[j] = a;
+                const unsigned long long m = __ballot(take[j]);
+                // previous flat element taken?  (bit lane-1 of this chunk's mask, or the last lane of the previous chunk)
+                const unsigned long long sh = (m << 1) | prev_last;
+                const bool prev_take = (sh >> lane) & 1ull;
+                prev_last = m >> 63;
+                const uint32_t ab = tab[tj[j]].z;                  // posting index of the batch's element 0 for this term's numbering
+                const uint32_t excl = (ab + p);                      // this element's posting index
+                const uint32_t wstart = tab[tj[j]].w;               // first posting index of the window
+                const bool first_untaken = (p < total) && !take[j] && (prev_take || excl == wstart);
+                if (first_untaken) inclv[tj[j]] = excl;
             }
-        }
-        uint2 pst[E];
-        float nrm[E], idfv[E], wqv[E];
-#pragma unroll
-        for (int j = 0; j < E; j++) {
-            const uint4 ent = tab[tj[j]];
-            const uint64_t addr = (((uint64_t)ent.y << 32) | ent.x) + (uint32_t)(j * 64 + lane);
-            idfv[j] = __uint_as_float(ent.z);
-            wqv[j] = __uint_as_float(ent.w);
-            pst[j] = make_uint2(0xFFFFFFFFu, 0u);
-            nrm[j] = 1.0f;
-            if (inb[j]) { pst[j] = postings[addr]; nrm[j] = pnorm[addr]; }
-        }
-
-        // ---- how much of each window is consumed (docId <= hi), cursor update ----
-        bool take[E];
-        uint32_t tmin[E], tmax[E];
-        uint32_t batch_consumed = 0;
-#pragma unroll
-        for (int j = 0; j < E; j++) {
-            take[j] = inb[j] && (pst[j].x <= hi);
-            tmin[j] = 1; tmax[j] = 0;
-            if ((uint32_t)(j * 64) < total) {   // uniform
-                const uint32_t last = min(63u, total - 1u - (uint32_t)(j * 64));
-                tmin[j] = rdlane(tj[j], 0);
-                tmax[j] = rdlane(tj[j], last);
-                for (uint32_t tt = tmin[j]; tt <= tmax[j]; tt++) {
-                    const uint32_t c = (uint32_t)__popcll(__ballot(take[j] && tj[j] == tt));
-                    if ((uint32_t)lane == tt) cur += c;
-                    batch_consumed += c;
-                }
+            wave_sync();
+            uint32_t consumed_t = 0;
+            if ((uint32_t)lane < T) {
+                const uint32_t ncur = inclv[lane] - base;
+                consumed_t = ncur - cur;
+                cur = ncur;
             }
+            // batch_consumed = sum over terms (DPP reduction, result in lane 63)
+            uint32_t c = consumed_t;
+            c += dpp_mov<0x111, 0xf>(0u, c);
+            c += dpp_mov<0x112, 0xf>(0u, c);
+            c += dpp_mov<0x114, 0xf>(0u, c);
+            c += dpp_mov<0x118, 0xf>(0u, c);
+            c += dpp_mov<0x142, 0xa>(0u, c);
+            c += dpp_mov<0x143, 0xc>(0u, c);
+            batch_consumed = rdlane(c, 63);
         }
-        const uint32_t w_done = w;
-        if (batch_consumed == 0) {   // only with corrupt lists (docIds beyond the range): skip the windows
-            cur += w_done;
+        if ((ABL & 16) || batch_consumed == 0) {   // only with corrupt lists (docIds beyond the range): skip the windows
+            cur += w;
             batch_consumed = total;
         }
         R = (R > batch_consumed) ? (R - batch_consumed) : 0;
+        const bool done = (R == 0) || (hi >= last_doc);
         // plan the next batch now: its docId probes fly while this batch is scored and read back
-        if (R > 0) plan_windows();
+        if (!done) NS_PLAN_WINDOWS();
 
         // ---- BM25 term scores, table insert, ordered accumulation ----
 #pragma unroll
         for (int j = 0; j < E; j++) {
             if ((uint32_t)(j * 64) >= total) continue;   // uniform
-            // p.x < lo only for corrupt (unsorted) lists: such postings are consumed, not scored
+            const uint4 ent = tab[tj[j]];
+            // docId < lo only for corrupt (unsorted) lists: such postings are consumed, not scored
             const bool ok = take[j] && (pst[j].x >= lo);
             // src/api_engine.cpp:477-480, operation for operation (k1 + 1.0f == 0x400CCCCD)
             const float tf = (float)pst[j].y;
             const float denom = tf + nrm[j];
-            const float sc = (idfv[j] * (tf * (1.2f + 1.0f))) / denom;
-            const float x = wqv[j] * sc;
+            const float sc = (ABL & 1) ? (__uint_as_float(ent.x) * (tf * (1.2f + 1.0f))) * __builtin_amdgcn_rcpf(denom)
+                                       : (__uint_as_float(ent.x) * (tf * (1.2f + 1.0f))) / denom;
+            const float x = __uint_as_float(ent.y) * sc;
             uint32_t slot = pst[j].x - lo;
+            if (ABL & 2) { asm volatile("" ::"v"(x), "v"(slot)); continue; }
             if (!direct && ok) {
                 slot = (pst[j].x * 2654435761u) >> (32 - LOG2HB);
                 for (int probe = 0; probe < HB; probe++) {
@@ -315,59 +388,59 @@ __global__ void __launch_bounds__(256) k_wscore(const DevWItem* __restrict__ ite
                     slot = (slot + 1) & (HB - 1);
                 }
             }
-            if (tmax[j] <= 1 || tmin[j] == tmax[j]) {
-                // one term, or only terms 0 and 1 (which commute exactly: (-0 + a) + b == (-0 + b) + a)
+            // LDS float atomics (ds_add_f32) run at ~1 lane per 3 clocks on gfx950 (measured: 70 % of
+            // this kernel's time); docIds are unique inside a term, so a plain read-add-write per
+            // term is race-free and the wave's LDS operations execute in order.
+            if (tmin[j] == tmax[j]) {
                 if (ok) {
-                    atomicAdd(&vals[slot], x);   // ds_add_f32
+                    vals[slot] = vals[slot] + x;
                     if (AND) atomicAdd(&mcnt[slot >> 2], 1u << ((slot & 3) * 8));
                 }
             } else {
-                // several terms inside one 64-lane chunk: issue the adds term by term (query-term order)
+                // several terms inside one 64-lane chunk: one read-add-write per term, in query-term
+                // order (the fp32 accumulation order of src/api_engine.cpp:480)
                 for (uint32_t tt = tmin[j]; tt <= tmax[j]; tt++) {
                     if (ok && tj[j] == tt) {
-                        atomicAdd(&vals[slot], x);
+                        vals[slot] = vals[slot] + x;
                         if (AND) atomicAdd(&mcnt[slot >> 2], 1u << ((slot & 3) * 8));
                     }
+                    wave_sync();
                 }
             }
         }
 
-        // ---- read the table back: found, candidates, reset ----
+        // ---- read the table back: found, candidates (rare: rolled slow path), reset ----
         wave_sync();
-        bool ge_mode = false;   // after a shrink INSIDE this batch, ties with theta may still win on docId
+        if (ABL & 4) { if (done) break; lo = hi + 1; continue; }
+        float4 q[NG];
+        bool anyq = false;
 #pragma unroll
         for (int g = 0; g < NG; g++) {
-            const float4 q = v4[g * 64 + lane];
-            uint4 kk = empty4;
-            if (!direct) kk = k4[g * 64 + lane];
+            q[g] = v4[g * 64 + lane];
             uint32_t cw = 0;
             if (AND) cw = mcnt[g * 64 + lane];
-            const float vv[4] = {q.x, q.y, q.z, q.w};
-            const uint32_t kd[4] = {kk.x, kk.y, kk.z, kk.w};
-            bool any = false;
+            const float vv[4] = {q[g].x, q[g].y, q[g].z, q[g].w};
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 bool touched = __float_as_uint(vv[c]) != kSentinelBits;
-                any = any || touched || (kd[c] != EMPTY);
                 if (AND) touched = touched && (((cw >> (8 * c)) & 0xFFu) == T);
-                found += (uint32_t)__popcll(__ballot(touched));
-                bool qf = touched && (ge_mode ? (vv[c] >= theta) : (vv[c] > theta));
-                unsigned long long mask = __ballot(qf);
-                if (mask != 0ull) {
-                    uint32_t n = (uint32_t)__popcll(mask);
-                    if (ncand + n > (uint32_t)CB) {
-                        ncand = wave_shrink(cand, ncand, theta, K, lane);
-                        ge_mode = true;
-                        qf = touched && (vv[c] >= theta);
-                        mask = __ballot(qf);
-                        n = (uint32_t)__popcll(mask);
-                    }
-                    if (qf) {
-                        const uint32_t doc = direct ? (lo + (uint32_t)((g * 64 + lane) * 4 + c)) : kd[c];
-                        cand[ncand + lanes_below(mask)] = make_key(vv[c], doc);
-                    }
-                    ncand += n;
-                }
+                found_lane += touched ? 1u : 0u;
+                anyq = anyq || (touched && vv[c] > theta);
+            }
+        }
+        if (__ballot(anyq) != 0ull) {
+            const uint64_t r = wave_collect<HB, AND>(vals, keys, mcnt, cand, lo, direct ? 1u : 0u, __float_as_uint(theta), ncand, K, T, lane);
+            theta = __uint_as_float((uint32_t)(r >> 32));
+            ncand = (uint32_t)r;
+        }
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            // every touched slot must be reset; untouched ones already hold the sentinel / EMPTY
+            bool any = (__float_as_uint(q[g].x) != kSentinelBits) || (__float_as_uint(q[g].y) != kSentinelBits) ||
+                       (__float_as_uint(q[g].z) != kSentinelBits) || (__float_as_uint(q[g].w) != kSentinelBits);
+            if (!direct) {
+                const uint4 kk = k4[g * 64 + lane];
+                any = any || ((kk.x & kk.y & kk.z & kk.w) != EMPTY);
             }
             if (any) {
                 v4[g * 64 + lane] = sent4;
@@ -376,10 +449,10 @@ __global__ void __launch_bounds__(256) k_wscore(const DevWItem* __restrict__ ite
             }
         }
         wave_sync();
-        if (ncand > (uint32_t)(CB / 2)) ncand = wave_shrink(cand, ncand, theta, K, lane);
-        if (hi >= last_doc) break;
+        if (done) break;
         lo = hi + 1;
     }
+#undef NS_PLAN_WINDOWS
 
     // ---- this item's top-K ----
     wave_sync();
@@ -400,7 +473,14 @@ __global__ void __launch_bounds__(256) k_wscore(const DevWItem* __restrict__ ite
         }
         oh[i] = h;
     }
-    if (lane == 0) {
+    uint32_t found = found_lane;
+    found += dpp_mov<0x111, 0xf>(0u, found);
+    found += dpp_mov<0x112, 0xf>(0u, found);
+    found += dpp_mov<0x114, 0xf>(0u, found);
+    found += dpp_mov<0x118, 0xf>(0u, found);
+    found += dpp_mov<0x142, 0xa>(0u, found);
+    found += dpp_mov<0x143, 0xc>(0u, found);
+    if (lane == 63) {
         out_nhits[it.out_slot] = n;
         out_found[it.out_slot] = (uint64_t)found;
     }
