@@ -68,42 +68,33 @@ static int fail(ns_ctx* ctx, int code, const char* fmt, ...) {
 //   wave variants (k_wscore): hb = accumulator-table entries per wave (batch = hb/2 postings)
 //   workgroup variants (k_score, the >64-terms fallback and the round-1 baseline): threads per
 //   workgroup, slots per thread, postings per thread per round; tile_docs = nt * spt.
-struct VariantDesc { uint32_t hb; uint32_t nt, spt, u; };
+struct VariantDesc { uint32_t hb; uint32_t nt, spt, u; uint32_t d; };
 static const VariantDesc kVariants[] = {
-    {512, 512, 12, 4},    // 0: default = wave kernel, 512-entry tables
-    {0, 1024, 12, 4},     // 1: workgroup kernel, 12288-doc tiles
-    {0, 512, 12, 4},      // 2: workgroup kernel,  6144-doc tiles
-    {0, 256, 16, 4},      // 3: workgroup kernel,  4096-doc tiles
-    {0, 512, 16, 8},      // 4: workgroup kernel,  8192-doc tiles
-    {256, 512, 12, 4},    // 5: wave kernel, 256-entry tables
-    {512, 512, 12, 4},    // 6: wave kernel, 512-entry tables
-    {1024, 512, 12, 4},   // 7: wave kernel, 1024-entry tables
-    // diagnostic ablations of variant 0 (results are wrong by construction; never used by the product)
-    {512, 512, 12, 4},    // 8: approximate division
-    {512, 512, 12, 4},    // 9: no table adds
-    {512, 512, 12, 4},    // 10: no read-back
-    {512, 512, 12, 4},    // 11: no norm load
-    {512, 512, 12, 4},    // 12: no consumed counting
-    {512, 512, 12, 4},    // 13: 1+2+4+8+16
+    {512, 512, 12, 4, 512},     // 0: default = wave kernel, 512 hash keys / 512 direct slots
+    {0, 1024, 12, 4, 0},        // 1: workgroup kernel, 12288-doc tiles
+    {0, 512, 12, 4, 0},         // 2: workgroup kernel,  6144-doc tiles
+    {0, 256, 16, 4, 0},         // 3: workgroup kernel,  4096-doc tiles
+    {0, 512, 16, 8, 0},         // 4: workgroup kernel,  8192-doc tiles
+    {256, 512, 12, 4, 256},     // 5: wave kernel, 256 keys / 256 direct slots
+    {512, 512, 12, 4, 512},     // 6: wave kernel, 512 / 512
+    {1024, 512, 12, 4, 1024},   // 7: wave kernel, 1024 / 1024
+    {512, 512, 12, 4, 1024},    // 8: wave kernel, 512 keys / 1024 direct slots
+    {512, 512, 12, 4, 2048},    // 9: wave kernel, 512 keys / 2048 direct slots
+    {256, 512, 12, 4, 1024},    // 10: wave kernel, 256 keys / 1024 direct slots
+    {256, 512, 12, 4, 2048},    // 11: wave kernel, 256 keys / 2048 direct slots
 };
 static constexpr uint32_t kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 static constexpr uint32_t kWaveMaxTerms = 64;
 static constexpr uint32_t kDefaultSplitPostings = 32768;
 
-template <int ABL>
-static void launch_wscore_abl(uint32_t n_items, hipStream_t st, const DevWItem* items, const DevTerm* terms,
-                              const DevSeg* segs, Hit* hits, uint32_t* nhits, uint64_t* found, uint32_t K) {
-    hipLaunchKernelGGL((k_wscore<512, false, ABL>), dim3((n_items + 3) / 4), dim3(256), 0, st, items, n_items, terms, segs, hits, nhits, found, K);
-}
-
-template <int HB>
+template <int D, int HK>
 static void launch_wscore(bool and_mode, uint32_t n_items, hipStream_t st, const DevWItem* items, const DevTerm* terms,
                           const DevSeg* segs, Hit* hits, uint32_t* nhits, uint64_t* found, uint32_t K) {
     dim3 grid((n_items + 3) / 4), block(256);
     if (and_mode)
-        hipLaunchKernelGGL((k_wscore<HB, true>), grid, block, 0, st, items, n_items, terms, segs, hits, nhits, found, K);
+        hipLaunchKernelGGL((k_wscore<D, HK, true>), grid, block, 0, st, items, n_items, terms, segs, hits, nhits, found, K);
     else
-        hipLaunchKernelGGL((k_wscore<HB, false>), grid, block, 0, st, items, n_items, terms, segs, hits, nhits, found, K);
+        hipLaunchKernelGGL((k_wscore<D, HK, false>), grid, block, 0, st, items, n_items, terms, segs, hits, nhits, found, K);
 }
 
 template <int NT, int SPT, int U>
@@ -561,21 +552,17 @@ extern "C" int ns_batch_run(ns_batch* b, int timed) {
     Hit* sh = b->direct ? b->o_hits : b->d_part_hits;
     uint32_t* sn = b->direct ? b->o_nhits : b->d_part_nhits;
     uint64_t* sf = b->direct ? b->o_found : b->d_part_found;
-    if (b->n_witems && b->variant >= 8) {
-        switch (b->variant) {
-            case 8: launch_wscore_abl<1>(b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K); break;
-            case 9: launch_wscore_abl<2>(b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K); break;
-            case 10: launch_wscore_abl<4>(b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K); break;
-            case 11: launch_wscore_abl<8>(b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K); break;
-            case 12: launch_wscore_abl<16>(b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K); break;
-            default: launch_wscore_abl<31>(b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K); break;
-        }
-    } else if (b->n_witems) {
-        switch (b->hb) {
-            case 256: launch_wscore<256>(and_mode, b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K); break;
-            case 1024: launch_wscore<1024>(and_mode, b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K); break;
-            default: launch_wscore<512>(and_mode, b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K); break;
-        }
+    if (b->n_witems) {
+        const VariantDesc wv = kVariants[b->variant];
+#define NS_W(DD, HH) launch_wscore<DD, HH>(and_mode, b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K)
+        if (wv.hb == 256 && wv.d == 256) NS_W(256, 256);
+        else if (wv.hb == 256 && wv.d == 1024) NS_W(1024, 256);
+        else if (wv.hb == 256 && wv.d == 2048) NS_W(2048, 256);
+        else if (wv.hb == 1024) NS_W(1024, 1024);
+        else if (wv.d == 1024) NS_W(1024, 512);
+        else if (wv.d == 2048) NS_W(2048, 512);
+        else NS_W(512, 512);
+#undef NS_W
     }
     if (b->n_items) {
         const VariantDesc vd = kVariants[b->variant];

@@ -118,68 +118,34 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
     return v;
 }
 
-// Slow half of the read-back: some slot beats theta.  Re-reads the (not yet reset) table with rolled
-// loops so that the common path stays short.  Returns (theta bits << 32) | ncand.
-template <int HB, bool AND>
-__device__ __noinline__ uint64_t wave_collect(const float* vals, const uint32_t* keys, const uint32_t* mcnt, uint64_t* cand,
-                                              uint32_t lo, uint32_t direct, uint32_t theta_bits, uint32_t ncand, uint32_t K,
-                                              uint32_t T, int lane) {
-    constexpr int CB = 256;
-    float theta = __uint_as_float(theta_bits);
-    bool ge_mode = false;   // after a shrink INSIDE this batch, ties with theta may still win on docId
-#pragma unroll 1
-    for (int i = 0; i < HB / 64; i++) {
-        const uint32_t slot = (uint32_t)(i * 64 + lane);
-        const float v = vals[slot];
-        bool touched = __float_as_uint(v) != kSentinelBits;
-        if (AND) touched = touched && (((mcnt[slot >> 2] >> (8 * (slot & 3))) & 0xFFu) == T);
-        bool qf = touched && (ge_mode ? (v >= theta) : (v > theta));
-        unsigned long long mask = __ballot(qf);
-        if (mask == 0ull) continue;
-        uint32_t n = (uint32_t)__popcll(mask);
-        if (ncand + n > (uint32_t)CB) {
-            ncand = wave_shrink(cand, ncand, theta, K, lane);
-            ge_mode = true;
-            qf = touched && (v >= theta);
-            mask = __ballot(qf);
-            n = (uint32_t)__popcll(mask);
-        }
-        if (qf) cand[ncand + lanes_below(mask)] = make_key(v, direct ? (lo + slot) : keys[slot]);
-        ncand += n;
-    }
-    wave_sync();
-    if (ncand > (uint32_t)(CB / 2)) ncand = wave_shrink(cand, ncand, theta, K, lane);
-    return ((uint64_t)__float_as_uint(theta) << 32) | ncand;
-}
-
 typedef unsigned int nat_u2 __attribute__((ext_vector_type(2)));
 // explicit global address space: pointers loaded from a descriptor are generic to the compiler, and
 // generic (flat_*) loads also tick lgkmcnt, which would serialise them with the LDS phases
 typedef const __attribute__((address_space(1))) nat_u2* gp_u2;
 typedef const __attribute__((address_space(1))) float* gp_f32;
 
-// ABL: diagnostic ablation bits (0 in every shipped path; results are WRONG when non-zero):
-//   1 approximate division, 2 no table adds, 4 no read-back, 8 no norm load, 16 no consumed counting
-template <int HB, bool AND, int ABL = 0>
+// D   direct-mapped accumulator slots per wave (a batch spanning <= D docs needs no hashing)
+// HK  hash keys per wave (<= D); a batch holds at most HK/2 postings
+template <int D, int HK, bool AND>
 __global__ void __launch_bounds__(256) k_wscore(const DevWItem* __restrict__ items, uint32_t n_items,
                                                 const DevTerm* __restrict__ terms, const DevSeg* __restrict__ segs,
                                                 Hit* __restrict__ out_hits, uint32_t* __restrict__ out_nhits,
                                                 uint64_t* __restrict__ out_found, uint32_t K) {
     constexpr int WPB = 4;                 // independent waves per workgroup
     constexpr int CB = 256;                // candidate buffer entries (>= NS_MAX_K + 64, power of two)
-    constexpr int BUDGET = HB / 2;         // postings per batch (hash load factor <= 1/2)
+    constexpr int BUDGET = HK / 2;         // postings per batch (hash load factor <= 1/2)
     constexpr int E = BUDGET / 64;         // postings per lane per batch
-    constexpr int NG = HB / 256;           // float4 groups per lane
-    constexpr int LOG2HB = (HB == 256) ? 8 : (HB == 512 ? 9 : (HB == 1024 ? 10 : 11));
+    constexpr int LOG2HK = (HK == 256) ? 8 : (HK == 512 ? 9 : (HK == 1024 ? 10 : 11));
     constexpr uint32_t EMPTY = 0xFFFFFFFFu;
-    static_assert(HB == 256 || HB == 512 || HB == 1024 || HB == 2048, "HB must be 256..2048");
+    static_assert(HK == 256 || HK == 512 || HK == 1024 || HK == 2048, "HK must be 256..2048");
+    static_assert(D >= HK && D % 256 == 0, "D must be a multiple of 256 and >= HK");
 
-    __shared__ __attribute__((aligned(16))) float s_vals[WPB][HB];
-    __shared__ __attribute__((aligned(16))) uint32_t s_keys[WPB][HB];
-    __shared__ __attribute__((aligned(16))) uint32_t s_mcnt[WPB][AND ? HB / 4 : 4];
+    __shared__ __attribute__((aligned(16))) float s_vals[WPB][D];
+    __shared__ __attribute__((aligned(16))) uint32_t s_keys[WPB][HK];
+    __shared__ __attribute__((aligned(16))) uint8_t s_mcnt[WPB][AND ? D : 16];   // AND: term refs that hit the slot
     __shared__ uint64_t s_cand[WPB][CB];
-    __shared__ __attribute__((aligned(16))) uint4 s_tab[WPB][64];   // per term: {idf, qweight, first posting - excl prefix, -}
-    __shared__ uint32_t s_incl[WPB][64];                             // inclusive prefix of window sizes (T > 8 lookups)
+    __shared__ __attribute__((aligned(16))) uint4 s_tab[WPB][64];   // per term: {idf, qweight, first posting - excl prefix, first posting}
+    __shared__ uint32_t s_aux[WPB][64];                              // T > 8: inclusive window prefix; then: new cursors
 
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
@@ -188,10 +154,10 @@ __global__ void __launch_bounds__(256) k_wscore(const DevWItem* __restrict__ ite
 
     float* vals = s_vals[wave];
     uint32_t* keys = s_keys[wave];
-    uint32_t* mcnt = s_mcnt[wave];
+    uint8_t* mcnt = s_mcnt[wave];
     uint64_t* cand = s_cand[wave];
     uint4* tab = s_tab[wave];
-    uint32_t* inclv = s_incl[wave];
+    uint32_t* aux = s_aux[wave];
 
     const DevWItem it = items[item_idx];
     const DevSeg seg = segs[it.seg];
@@ -199,16 +165,21 @@ __global__ void __launch_bounds__(256) k_wscore(const DevWItem* __restrict__ ite
     const gp_u2 postings = (gp_u2)seg.postings;
     const gp_f32 pnorm = (gp_f32)seg.pnorm;
 
-    const float4 sent4 = make_float4(__uint_as_float(kSentinelBits), __uint_as_float(kSentinelBits),
-                                     __uint_as_float(kSentinelBits), __uint_as_float(kSentinelBits));
-    const uint4 empty4 = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
-    float4* v4 = reinterpret_cast<float4*>(vals);
-    uint4* k4 = reinterpret_cast<uint4*>(keys);
+    {
+        const float4 sent4 = make_float4(__uint_as_float(kSentinelBits), __uint_as_float(kSentinelBits),
+                                         __uint_as_float(kSentinelBits), __uint_as_float(kSentinelBits));
+        const uint4 empty4 = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+        float4* v4 = reinterpret_cast<float4*>(vals);
+        uint4* k4 = reinterpret_cast<uint4*>(keys);
 #pragma unroll
-    for (int g = 0; g < NG; g++) {
-        v4[g * 64 + lane] = sent4;
-        k4[g * 64 + lane] = empty4;
-        if (AND) mcnt[g * 64 + lane] = 0;
+        for (int g = 0; g < D / 256; g++) v4[g * 64 + lane] = sent4;
+#pragma unroll
+        for (int g = 0; g < HK / 256; g++) k4[g * 64 + lane] = empty4;
+        if (AND) {
+            uint32_t* m32 = reinterpret_cast<uint32_t*>(mcnt);
+#pragma unroll
+            for (int g = 0; g < D / 256; g++) m32[g * 64 + lane] = 0;
+        }
     }
 
     // ---- lane t owns term t (posting indices are 32-bit: upload rejects segments of >= 2^32 postings) ----
@@ -237,7 +208,7 @@ __global__ void __launch_bounds__(256) k_wscore(const DevWItem* __restrict__ ite
     const uint32_t last_doc = it.doc_hi - 1;   // host guarantees doc_hi > doc_lo and doc_hi <= n_docs
     float theta = -__builtin_inff();
     uint32_t ncand = 0;
-    uint32_t found_lane = 0;   // per-lane count of touched slots, reduced once at the end
+    uint32_t found_lane = 0;   // per-lane count of scored docs, reduced once at the end
 
     // Window sizes proportional to what is left of each list (so all windows span about the same doc
     // range; Sum(w) <= BUDGET + fp slop << the table's spare half) + the probe of each window's last
@@ -264,10 +235,10 @@ __global__ void __launch_bounds__(256) k_wscore(const DevWItem* __restrict__ ite
         const uint32_t incl = wave_incl_scan_dpp(w);
         const uint32_t total = rdlane(incl, 63);
         if ((uint32_t)lane < T) tab[lane] = make_uint4(idf_bits, wq_bits, base + cur - (incl - w), base + cur);
-        if (T > 8) inclv[lane] = incl;
+        if (T > 8) aux[lane] = incl;
         uint32_t hi = wave_min_dpp(e);   // every posting with docId <= hi of every term is inside its window
         hi = min(hi, last_doc);
-        const bool direct = (hi >= lo) && ((hi - lo) < (uint32_t)HB);   // uniform
+        const bool direct = (hi >= lo) && ((hi - lo) < (uint32_t)D);   // uniform
         wave_sync();
 
         // ---- flat, coalesced loads of the whole batch (all in flight together, no branches:
@@ -289,22 +260,24 @@ __global__ void __launch_bounds__(256) k_wscore(const DevWItem* __restrict__ ite
                     uint32_t a = 0, b = T - 1;   // smallest t with incl[t] > p
                     while (a < b) {
                         const uint32_t m = (a + b) >> 1;
-                        if (inclv[m] > p) b = m; else a = m + 1;
+                        if (aux[m] > p) b = m; else a = m + 1;
                     }
                     tj[j] = a;
                 }
+                wave_sync();   // aux is reused below
             }
         }
         nat_u2 pst[E];
         float nrm[E];
+        uint32_t pidx[E];
 #pragma unroll
         for (int j = 0; j < E; j++) {
             const uint32_t p = (uint32_t)(j * 64 + lane);
             const bool inb = p < total;
             tj[j] = inb ? tj[j] : 0u;
-            const uint32_t idx = tab[tj[j]].z + (inb ? p : 0u);
-            pst[j] = postings[idx];
-            nrm[j] = (ABL & 8) ? 1.0f : pnorm[idx];
+            pidx[j] = tab[tj[j]].z + (inb ? p : 0u);
+            pst[j] = postings[pidx[j]];
+            nrm[j] = pnorm[pidx[j]];
             pst[j].x = inb ? pst[j].x : 0xFFFFFFFFu;   // docId ~0 is never <= hi
         }
 
@@ -313,41 +286,29 @@ __global__ void __launch_bounds__(256) k_wscore(const DevWItem* __restrict__ ite
         // that is NOT taken (or nothing, if all are) marks the new cursor.  That lane is unique per
         // term, so it publishes its posting index with a plain LDS store; no per-term ballot loops.
         bool take[E];
-        uint32_t tmin[E], tmax[E];
         uint32_t batch_consumed;
         {
-            if ((uint32_t)lane < T) inclv[lane] = base + cur + w;   // default: whole window consumed
+            if ((uint32_t)lane < T) aux[lane] = base + cur + w;   // default: whole window consumed
             wave_sync();
             unsigned long long prev_last = 1ull;   // "element before the batch" counts as taken
 #pragma unroll
             for (int j = 0; j < E; j++) {
-                const uint32_t p = (uint32_t)(j * 64 + lane);
                 take[j] = pst[j].x <= hi;
-                tmin[j] = 0; tmax[j] = 0;
-                if (T > 1 && (uint32_t)(j * 64) < total) {   // uniform
-                    tmin[j] = rdlane(tj[j], 0);
-                    tmax[j] = rdlane(tj[j], min(63u, total - 1u - (uint32_t)(j * 64)));
-                }
                 const unsigned long long m = __ballot(take[j]);
                 // previous flat element taken?  (bit lane-1 of this chunk's mask, or the last lane of the previous chunk)
-                const unsigned long long sh = (m << 1) | prev_last;
-                const bool prev_take = (sh >> lane) & 1ull;
+                const bool prev_take = (((m << 1) | prev_last) >> lane) & 1ull;
                 prev_last = m >> 63;
-                const uint32_t ab = tab[tj[j]].z;                  // posting index of the batch's element 0 for this term's numbering
-                const uint32_t excl = (ab + p);                      // this element's posting index
-                const uint32_t wstart = tab[tj[j]].w;               // first posting index of the window
-                const bool first_untaken = (p < total) && !take[j] && (prev_take || excl == wstart);
-                if (first_untaken) inclv[tj[j]] = excl;
+                const bool first_untaken = ((uint32_t)(j * 64 + lane) < total) && !take[j] &&
+                                           (prev_take || pidx[j] == tab[tj[j]].w);
+                if (first_untaken) aux[tj[j]] = pidx[j];
             }
             wave_sync();
-            uint32_t consumed_t = 0;
+            uint32_t c = 0;
             if ((uint32_t)lane < T) {
-                const uint32_t ncur = inclv[lane] - base;
-                consumed_t = ncur - cur;
+                const uint32_t ncur = aux[lane] - base;
+                c = ncur - cur;
                 cur = ncur;
             }
-            // batch_consumed = sum over terms (DPP reduction, result in lane 63)
-            uint32_t c = consumed_t;
             c += dpp_mov<0x111, 0xf>(0u, c);
             c += dpp_mov<0x112, 0xf>(0u, c);
             c += dpp_mov<0x114, 0xf>(0u, c);
@@ -356,8 +317,9 @@ __global__ void __launch_bounds__(256) k_wscore(const DevWItem* __restrict__ ite
             c += dpp_mov<0x143, 0xc>(0u, c);
             batch_consumed = rdlane(c, 63);
         }
-        if ((ABL & 16) || batch_consumed == 0) {   // only with corrupt lists (docIds beyond the range): skip the windows
+        if (batch_consumed == 0) {   // only with corrupt lists (docIds beyond the range): skip the windows
             cur += w;
+            if (cur > end) cur = end;
             batch_consumed = total;
         }
         R = (R > batch_consumed) ? (R - batch_consumed) : 0;
@@ -365,90 +327,129 @@ __global__ void __launch_bounds__(256) k_wscore(const DevWItem* __restrict__ ite
         // plan the next batch now: its docId probes fly while this batch is scored and read back
         if (!done) NS_PLAN_WINDOWS();
 
-        // ---- BM25 term scores, table insert, ordered accumulation ----
+        // ---- BM25 term scores + table slots ----
+        float x[E];
+        uint32_t slot[E];
+        bool ok[E];
+        // terms present in the batch (uniform): first element's term .. last element's term
+        uint32_t tb_min = 0, tb_max = 0;
+        if (T > 1) {
+            tb_min = rdlane(tj[0], 0);
+            const uint32_t lastp = total - 1u;
+            uint32_t tl = 0;
+#pragma unroll
+            for (int j = 0; j < E; j++)
+                if ((lastp >> 6) == (uint32_t)j) tl = rdlane(tj[j], lastp & 63u);   // uniform
+            tb_max = tl;
+        }
 #pragma unroll
         for (int j = 0; j < E; j++) {
-            if ((uint32_t)(j * 64) >= total) continue;   // uniform
             const uint4 ent = tab[tj[j]];
             // docId < lo only for corrupt (unsorted) lists: such postings are consumed, not scored
-            const bool ok = take[j] && (pst[j].x >= lo);
+            ok[j] = take[j] && (pst[j].x >= lo);
             // src/api_engine.cpp:477-480, operation for operation (k1 + 1.0f == 0x400CCCCD)
             const float tf = (float)pst[j].y;
             const float denom = tf + nrm[j];
-            const float sc = (ABL & 1) ? (__uint_as_float(ent.x) * (tf * (1.2f + 1.0f))) * __builtin_amdgcn_rcpf(denom)
-                                       : (__uint_as_float(ent.x) * (tf * (1.2f + 1.0f))) / denom;
-            const float x = __uint_as_float(ent.y) * sc;
-            uint32_t slot = pst[j].x - lo;
-            if (ABL & 2) { asm volatile("" ::"v"(x), "v"(slot)); continue; }
-            if (!direct && ok) {
-                slot = (pst[j].x * 2654435761u) >> (32 - LOG2HB);
-                for (int probe = 0; probe < HB; probe++) {
-                    const uint32_t old = atomicCAS(&keys[slot], EMPTY, pst[j].x);
-                    if (old == EMPTY || old == pst[j].x) break;
-                    slot = (slot + 1) & (HB - 1);
-                }
-            }
-            // LDS float atomics (ds_add_f32) run at ~1 lane per 3 clocks on gfx950 (measured: 70 % of
-            // this kernel's time); docIds are unique inside a term, so a plain read-add-write per
-            // term is race-free and the wave's LDS operations execute in order.
-            if (tmin[j] == tmax[j]) {
-                if (ok) {
-                    vals[slot] = vals[slot] + x;
-                    if (AND) atomicAdd(&mcnt[slot >> 2], 1u << ((slot & 3) * 8));
-                }
-            } else {
-                // several terms inside one 64-lane chunk: one read-add-write per term, in query-term
-                // order (the fp32 accumulation order of src/api_engine.cpp:480)
-                for (uint32_t tt = tmin[j]; tt <= tmax[j]; tt++) {
-                    if (ok && tj[j] == tt) {
-                        vals[slot] = vals[slot] + x;
-                        if (AND) atomicAdd(&mcnt[slot >> 2], 1u << ((slot & 3) * 8));
-                    }
+            const float sc = (__uint_as_float(ent.x) * (tf * (1.2f + 1.0f))) / denom;
+            x[j] = __uint_as_float(ent.y) * sc;
+            slot[j] = pst[j].x - lo;
+        }
+        if (!direct) {
+            // Open-addressing claim WITHOUT LDS atomics (integer and float LDS atomics are serialised
+            // per lane on gfx950): read the key; if the slot is free store our docId and read it back —
+            // the wave's LDS operations execute in order, so exactly one of the colliding docIds
+            // survives the store and everybody else moves on.  Equal docIds (same doc, two terms)
+            // agree on the slot.
+#pragma unroll
+            for (int j = 0; j < E; j++) {
+                if ((uint32_t)(j * 64) >= total) continue;   // uniform
+                const uint32_t doc = pst[j].x;
+                uint32_t sl = (doc * 2654435761u) >> (32 - LOG2HK);
+                bool pending = ok[j];
+                for (int round = 0; round < HK; round++) {
+                    if (__ballot(pending) == 0ull) break;
+                    uint32_t k = EMPTY;
+                    if (pending) k = keys[sl];
+                    if (pending && k == EMPTY) keys[sl] = doc;
                     wave_sync();
+                    if (pending && k == EMPTY) k = keys[sl];
+                    if (pending && k == doc) pending = false;
+                    if (pending) sl = (sl + 1) & (HK - 1);
                 }
+                slot[j] = sl;
             }
         }
 
-        // ---- read the table back: found, candidates (rare: rolled slow path), reset ----
-        wave_sync();
-        if (ABL & 4) { if (done) break; lo = hi + 1; continue; }
-        float4 q[NG];
+        // ---- accumulate: one read-add-write per term, terms in query order (the fp32 order of
+        //      src/api_engine.cpp:480).  docIds are unique inside a term, so the plain RMW is race-free;
+        //      reading the sentinel back tells the FIRST posting of a doc that it owns the slot. ----
+        bool owner[E];
+#pragma unroll
+        for (int j = 0; j < E; j++) owner[j] = false;
+        for (uint32_t tt = tb_min; tt <= tb_max; tt++) {
+            float old[E];
+#pragma unroll
+            for (int j = 0; j < E; j++) {
+                old[j] = 0.0f;
+                if (ok[j] && tj[j] == tt) old[j] = vals[slot[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < E; j++) {
+                if (ok[j] && tj[j] == tt) {
+                    owner[j] = owner[j] || (__float_as_uint(old[j]) == kSentinelBits);
+                    vals[slot[j]] = old[j] + x[j];
+                    if (AND) mcnt[slot[j]] = (uint8_t)(mcnt[slot[j]] + 1);
+                }
+            }
+            wave_sync();
+        }
+
+        // ---- read back through the owners: found (:495), candidates above theta (:485-492), reset ----
+        float fin[E];
+        bool scored[E];
         bool anyq = false;
 #pragma unroll
-        for (int g = 0; g < NG; g++) {
-            q[g] = v4[g * 64 + lane];
-            uint32_t cw = 0;
-            if (AND) cw = mcnt[g * 64 + lane];
-            const float vv[4] = {q[g].x, q[g].y, q[g].z, q[g].w};
+        for (int j = 0; j < E; j++) {
+            fin[j] = 0.0f;
+            scored[j] = owner[j];
+            if (owner[j]) {
+                fin[j] = vals[slot[j]];
+                if (AND) scored[j] = (mcnt[slot[j]] == (uint8_t)T);   // conjunctive extension: every term ref hit the doc
+            }
+        }
+        wave_sync();
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                bool touched = __float_as_uint(vv[c]) != kSentinelBits;
-                if (AND) touched = touched && (((cw >> (8 * c)) & 0xFFu) == T);
-                found_lane += touched ? 1u : 0u;
-                anyq = anyq || (touched && vv[c] > theta);
+        for (int j = 0; j < E; j++) {
+            found_lane += scored[j] ? 1u : 0u;
+            anyq = anyq || (scored[j] && fin[j] > theta);
+            if (owner[j]) {   // the first toucher resets the slot for the next batch
+                vals[slot[j]] = __uint_as_float(kSentinelBits);
+                if (!direct) keys[slot[j]] = EMPTY;
+                if (AND) mcnt[slot[j]] = 0;
             }
         }
         if (__ballot(anyq) != 0ull) {
-            const uint64_t r = wave_collect<HB, AND>(vals, keys, mcnt, cand, lo, direct ? 1u : 0u, __float_as_uint(theta), ncand, K, T, lane);
-            theta = __uint_as_float((uint32_t)(r >> 32));
-            ncand = (uint32_t)r;
-        }
+            bool ge_mode = false;   // after a shrink INSIDE this batch, ties with theta may still win on docId
 #pragma unroll
-        for (int g = 0; g < NG; g++) {
-            // every touched slot must be reset; untouched ones already hold the sentinel / EMPTY
-            bool any = (__float_as_uint(q[g].x) != kSentinelBits) || (__float_as_uint(q[g].y) != kSentinelBits) ||
-                       (__float_as_uint(q[g].z) != kSentinelBits) || (__float_as_uint(q[g].w) != kSentinelBits);
-            if (!direct) {
-                const uint4 kk = k4[g * 64 + lane];
-                any = any || ((kk.x & kk.y & kk.z & kk.w) != EMPTY);
+            for (int j = 0; j < E; j++) {
+                bool qf = scored[j] && (ge_mode ? (fin[j] >= theta) : (fin[j] > theta));
+                unsigned long long mask = __ballot(qf);
+                if (mask != 0ull) {
+                    uint32_t n = (uint32_t)__popcll(mask);
+                    if (ncand + n > (uint32_t)CB) {
+                        ncand = wave_shrink(cand, ncand, theta, K, lane);
+                        ge_mode = true;
+                        qf = scored[j] && (fin[j] >= theta);
+                        mask = __ballot(qf);
+                        n = (uint32_t)__popcll(mask);
+                    }
+                    if (qf) cand[ncand + lanes_below(mask)] = make_key(fin[j], pst[j].x);
+                    ncand += n;
+                }
             }
-            if (any) {
-                v4[g * 64 + lane] = sent4;
-                if (!direct) k4[g * 64 + lane] = empty4;
-                if (AND) mcnt[g * 64 + lane] = 0;
-            }
+            wave_sync();
+            if (ncand > (uint32_t)(CB / 2)) ncand = wave_shrink(cand, ncand, theta, K, lane);
         }
-        wave_sync();
         if (done) break;
         lo = hi + 1;
     }

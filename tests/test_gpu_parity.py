@@ -70,7 +70,7 @@ def test_gpu_equals_oracle_and_reference_golden(name, engines):
             assert [int(b) for b in gh[qi, : gn[qi]]["score"].view(np.uint32)] == [h[2] for h in ref["hits"]]
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 def test_kernel_variants_agree(variant, engines):
     """Wave-private kernel (5/6/7: 256/512/1024-entry tables) and workgroup-tile kernel (1..4)."""
     g, eng, ora = engines("mid1")
