@@ -108,6 +108,15 @@ __device__ __forceinline__ uint32_t wave_min_dpp(uint32_t v) {
     v = min(v, dpp_mov<0x143, 0xc>(0xFFFFFFFFu, v));   // row_bcast:31
     return rdlane(v, 63);
 }
+__device__ __forceinline__ uint32_t wave_max_dpp(uint32_t v) {
+    v = max(v, dpp_mov<0x111, 0xf>(0u, v));
+    v = max(v, dpp_mov<0x112, 0xf>(0u, v));
+    v = max(v, dpp_mov<0x114, 0xf>(0u, v));
+    v = max(v, dpp_mov<0x118, 0xf>(0u, v));
+    v = max(v, dpp_mov<0x142, 0xa>(0u, v));
+    v = max(v, dpp_mov<0x143, 0xc>(0u, v));
+    return rdlane(v, 63);
+}
 __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
     v += dpp_mov<0x111, 0xf>(0u, v);
     v += dpp_mov<0x112, 0xf>(0u, v);
@@ -213,7 +222,7 @@ __global__ void __launch_bounds__(256) k_wscore(const DevWItem* __restrict__ ite
     // Window sizes proportional to what is left of each list (so all windows span about the same doc
     // range; Sum(w) <= BUDGET + fp slop << the table's spare half) + the probe of each window's last
     // docId.  Planned one batch ahead: the probe flies while the current batch is scored.
-    uint32_t w = 0, e = 0xFFFFFFFFu;
+    uint32_t w = 0, e = 0xFFFFFFFFu, f = 0xFFFFFFFFu;   // f: first docId left in the list (~0: exhausted)
 #define NS_PLAN_WINDOWS()                                                                          \
     {                                                                                              \
         const uint32_t rem_ = end - cur;                                                           \
@@ -223,15 +232,96 @@ __global__ void __launch_bounds__(256) k_wscore(const DevWItem* __restrict__ ite
         w_ = (w_ < rem_) ? w_ : rem_;                                                              \
         const bool probe_ = w_ < rem_;   /* false for lanes >= T (rem_ == 0) */                    \
         const uint32_t pi_ = probe_ ? (base + cur + w_ - 1u) : 0u;                                 \
-        const nat_u2 pv_ = postings[pi_];   /* unconditional load of a valid index: no branch */   \
+        const uint32_t fi_ = (rem_ > 0) ? (base + cur) : 0u;                                       \
+        const nat_u2 pv_ = postings[pi_];   /* unconditional loads of valid indices: no branch */  \
+        const nat_u2 fv_ = postings[fi_];                                                          \
         w = w_;                                                                                    \
         e = probe_ ? pv_.x : 0xFFFFFFFFu;                                                          \
+        f = (rem_ > 0) ? fv_.x : 0xFFFFFFFFu;                                                      \
     }
     if (R > 0) NS_PLAN_WINDOWS();
     wave_sync();
 
     while (R > 0) {
-        // ---- batch geometry ----
+        // ---- which terms take part in this batch ----
+        // The term with the most postings left drives the batch; its window ends at docId Ed.  A
+        // term whose next posting lies beyond Ed has nothing to add to the docs of this batch: it
+        // stays out (cursor untouched) and costs nothing.  With one hot list and a few sparse ones
+        // many batches are EXCLUSIVE to the hot list.
+        {
+            const uint32_t remv = end - cur;
+            const uint32_t mx = wave_max_dpp(remv);
+            const uint32_t dl = (uint32_t)__builtin_ctzll(__ballot(remv == mx));   // mx > 0 here (R > 0)
+            const uint32_t Ed = rdlane(e, dl);
+            const bool inc = (remv > 0) && ((uint32_t)lane == dl || f <= Ed);
+            w = inc ? w : 0u;
+            e = inc ? e : 0xFFFFFFFFu;
+            if (__popcll(__ballot(inc)) == 1 && Ed <= last_doc) {
+                // ---- exclusive batch: every doc of [lo, Ed] is touched by this one term only, so its
+                //      score is 0.0f + w*s == w*s exactly (src/api_engine.cpp:480): no table, no merge;
+                //      the whole window is consumed. ----
+                const uint32_t wd = rdlane(w, dl);
+                const uint32_t b0 = rdlane(base, dl) + rdlane(cur, dl);
+                const float idf = __uint_as_float(rdlane(idf_bits, dl));
+                const float wq = __uint_as_float(rdlane(wq_bits, dl));
+                nat_u2 ps[E];
+                float nr[E];
+#pragma unroll
+                for (int j = 0; j < E; j++) {
+                    const uint32_t p = (uint32_t)(j * 64 + lane);
+                    const uint32_t idx = b0 + ((p < wd) ? p : 0u);
+                    ps[j] = postings[idx];
+                    nr[j] = pnorm[idx];
+                }
+                if ((uint32_t)lane == dl) cur += wd;
+                R = (R > wd) ? (R - wd) : 0;
+                const bool xdone = (R == 0) || (Ed >= last_doc);
+                if (!xdone) NS_PLAN_WINDOWS();
+                float fin[E];
+                bool sc_[E];
+                bool anyq = false;
+#pragma unroll
+                for (int j = 0; j < E; j++) {
+                    const uint32_t p = (uint32_t)(j * 64 + lane);
+                    const float tf = (float)ps[j].y;
+                    const float denom = tf + nr[j];
+                    const float sc = (idf * (tf * (1.2f + 1.0f))) / denom;
+                    fin[j] = wq * sc;
+                    // docId outside [lo, Ed] only for corrupt (unsorted) lists: consumed, not scored
+                    sc_[j] = (p < wd) && (ps[j].x >= lo) && (ps[j].x <= Ed);
+                    if (AND && T > 1) sc_[j] = false;   // conjunctive extension: one term alone never qualifies
+                    found_lane += sc_[j] ? 1u : 0u;
+                    anyq = anyq || (sc_[j] && fin[j] > theta);
+                }
+                if (__ballot(anyq) != 0ull) {
+                    bool ge_mode = false;
+#pragma unroll
+                    for (int j = 0; j < E; j++) {
+                        bool qf = sc_[j] && (ge_mode ? (fin[j] >= theta) : (fin[j] > theta));
+                        unsigned long long mask = __ballot(qf);
+                        if (mask != 0ull) {
+                            uint32_t n = (uint32_t)__popcll(mask);
+                            if (ncand + n > (uint32_t)CB) {
+                                ncand = wave_shrink(cand, ncand, theta, K, lane);
+                                ge_mode = true;
+                                qf = sc_[j] && (fin[j] >= theta);
+                                mask = __ballot(qf);
+                                n = (uint32_t)__popcll(mask);
+                            }
+                            if (qf) cand[ncand + lanes_below(mask)] = make_key(fin[j], ps[j].x);
+                            ncand += n;
+                        }
+                    }
+                    wave_sync();
+                    if (ncand > (uint32_t)(CB / 2)) ncand = wave_shrink(cand, ncand, theta, K, lane);
+                }
+                if (xdone) break;
+                lo = Ed + 1;
+                continue;
+            }
+        }
+
+        // ---- batch geometry (shared batch: several terms have postings in its doc range) ----
         const uint32_t incl = wave_incl_scan_dpp(w);
         const uint32_t total = rdlane(incl, 63);
         if ((uint32_t)lane < T) tab[lane] = make_uint4(idf_bits, wq_bits, base + cur - (incl - w), base + cur);
