@@ -16,6 +16,7 @@
 #include "ns_internal.h"
 #include "ns_kernels.hip"
 #include "ns_wave_kernel.hip"
+#include "ns_driver_kernel.hip"
 
 using namespace ns;
 
@@ -70,7 +71,7 @@ static int fail(ns_ctx* ctx, int code, const char* fmt, ...) {
 //   workgroup, slots per thread, postings per thread per round; tile_docs = nt * spt.
 struct VariantDesc { uint32_t hb; uint32_t nt, spt, u; uint32_t d; };
 static const VariantDesc kVariants[] = {
-    {512, 512, 12, 4, 512},     // 0: default = wave kernel, 512 hash keys / 512 direct slots
+    {512, 512, 12, 4, 0},       // 0: default = driver-stream kernel k_dscore, 512 slots / 128 foreign postings (same as 12)
     {0, 1024, 12, 4, 0},        // 1: workgroup kernel, 12288-doc tiles
     {0, 512, 12, 4, 0},         // 2: workgroup kernel,  6144-doc tiles
     {0, 256, 16, 4, 0},         // 3: workgroup kernel,  4096-doc tiles
@@ -82,6 +83,12 @@ static const VariantDesc kVariants[] = {
     {512, 512, 12, 4, 2048},    // 9: wave kernel, 512 keys / 2048 direct slots
     {256, 512, 12, 4, 1024},    // 10: wave kernel, 256 keys / 1024 direct slots
     {256, 512, 12, 4, 2048},    // 11: wave kernel, 256 keys / 2048 direct slots
+    {512, 512, 12, 4, 0},       // 12: driver-stream kernel (k_dscore), 512 slots, 128 foreign postings per super-batch   [d == 0 marks k_dscore]
+    {256, 512, 12, 4, 0},       // 13: k_dscore  256 slots /  64 foreign
+    {1024, 512, 12, 4, 0},      // 14: k_dscore 1024 slots / 256 foreign
+    {512, 512, 12, 4, 0},       // 15: k_dscore  512 slots /  64 foreign
+    {512, 512, 12, 4, 0},       // 16: k_dscore  512 slots / 256 foreign
+    {1024, 512, 12, 4, 0},      // 17: k_dscore 1024 slots / 128 foreign
 };
 static constexpr uint32_t kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 static constexpr uint32_t kWaveMaxTerms = 64;
@@ -95,6 +102,16 @@ static void launch_wscore(bool and_mode, uint32_t n_items, hipStream_t st, const
         hipLaunchKernelGGL((k_wscore<D, HK, true>), grid, block, 0, st, items, n_items, terms, segs, hits, nhits, found, K);
     else
         hipLaunchKernelGGL((k_wscore<D, HK, false>), grid, block, 0, st, items, n_items, terms, segs, hits, nhits, found, K);
+}
+
+template <int HK, int FB>
+static void launch_dscore(bool and_mode, uint32_t n_items, hipStream_t st, const DevWItem* items, const DevTerm* terms,
+                          const DevSeg* segs, Hit* hits, uint32_t* nhits, uint64_t* found, uint32_t K) {
+    dim3 grid((n_items + 3) / 4), block(256);
+    if (and_mode)
+        hipLaunchKernelGGL((k_dscore<HK, FB, true>), grid, block, 0, st, items, n_items, terms, segs, hits, nhits, found, K);
+    else
+        hipLaunchKernelGGL((k_dscore<HK, FB, false>), grid, block, 0, st, items, n_items, terms, segs, hits, nhits, found, K);
 }
 
 template <int NT, int SPT, int U>
@@ -555,7 +572,19 @@ extern "C" int ns_batch_run(ns_batch* b, int timed) {
     if (b->n_witems) {
         const VariantDesc wv = kVariants[b->variant];
 #define NS_W(DD, HH) launch_wscore<DD, HH>(and_mode, b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K)
-        if (wv.hb == 256 && wv.d == 256) NS_W(256, 256);
+#define NS_D(HH, FF) launch_dscore<HH, FF>(and_mode, b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K)
+        if (wv.d == 0) {
+            switch (b->variant) {
+                case 13: NS_D(256, 64); break;
+                case 14: NS_D(1024, 256); break;
+                case 15: NS_D(512, 64); break;
+                case 16: NS_D(512, 256); break;
+                case 17: NS_D(1024, 128); break;
+                default: NS_D(512, 128); break;
+            }
+        }
+#undef NS_D
+        else if (wv.hb == 256 && wv.d == 256) NS_W(256, 256);
         else if (wv.hb == 256 && wv.d == 1024) NS_W(1024, 256);
         else if (wv.hb == 256 && wv.d == 2048) NS_W(2048, 256);
         else if (wv.hb == 1024) NS_W(1024, 1024);
