@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""End-to-end (PCIe- and host-inclusive) rates of the same batch that bench.py times device-only.
+Diagnostic; prints one line per stage.  GPU box only."""
+import os, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "nextsearch-api_amd"))
+import nsbind, workloads
+tmp = tempfile.TemporaryDirectory(); idx = os.path.join(tmp.name, "i")
+nsbind.gen_index(idx, 1, 1_000_000, 65536, 1337, False)
+t0 = time.perf_counter(); eng = nsbind.Engine(idx, 0); t1 = time.perf_counter()
+print(f"Engine.reload (load 83 MB index from disk + upload + norms): {t1 - t0:.3f} s")
+qs = workloads.cfg5_queries(); Q = len(qs)
+eng.search_batch(qs[:64], 10)
+for rep in range(3):
+    t0 = time.perf_counter(); qd, refs, usable = eng.build_refs(qs); t1 = time.perf_counter()
+    rc, hits, nhits, found = nsbind.search_batch_raw(eng.ctx, qd, refs, 10); t2 = time.perf_counter()
+    b = eng.prepare(qs, 10); t3 = time.perf_counter()
+    b.run(False); b.sync(); t4 = time.perf_counter()
+    b.fetch(); t5 = time.perf_counter(); b.close()
+    t6 = time.perf_counter(); eng.search_batch(qs, 10); t7 = time.perf_counter()
+    print(f"rep {rep}: query prep (tokenise+lexicon+idf) {1e3*(t1-t0):.1f} ms | ns_search_batch (host->host) {1e3*(t2-t1):.1f} ms = {Q/(t2-t1):.0f} q/s | "
+          f"prepare(incl. query prep) {1e3*(t3-t2):.1f} ms, run {1e3*(t4-t3):.2f} ms, fetch {1e3*(t5-t4):.2f} ms | facade search_batch {1e3*(t7-t6):.1f} ms = {Q/(t7-t6):.0f} q/s")
