@@ -201,7 +201,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_dscore" if args.variant in (0, 12, 13, 14, 15, 16, 17) else ("k_wscore" if args.variant in (5, 6, 7, 8, 9, 10, 11) else "k_score"),
+                "kernel": "k_uscore" if args.variant == 0 else "k_dscore" if args.variant in (12, 13, 14, 15, 16, 17) else "k_tscore" if args.variant in (18, 19, 20) else ("k_wscore" if args.variant in (5, 6, 7, 8, 9, 10, 11) else "k_score"),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -17,6 +18,7 @@
 #include "ns_kernels.hip"
 #include "ns_wave_kernel.hip"
 #include "ns_driver_kernel.hip"
+#include "ns_tile_kernel.hip"
 
 using namespace ns;
 
@@ -37,6 +39,8 @@ struct ns_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t aux_stream[2] = {nullptr, nullptr};   // the three item classes are scored concurrently
+    hipEvent_t fork_ev = nullptr, join_ev[2] = {nullptr, nullptr};
     std::string err;
     std::string devname;
     int n_cus = 0;
@@ -71,7 +75,7 @@ static int fail(ns_ctx* ctx, int code, const char* fmt, ...) {
 //   workgroup, slots per thread, postings per thread per round; tile_docs = nt * spt.
 struct VariantDesc { uint32_t hb; uint32_t nt, spt, u; uint32_t d; };
 static const VariantDesc kVariants[] = {
-    {512, 512, 12, 4, 0},       // 0: default = driver-stream kernel k_dscore, 512 slots / 128 foreign postings (same as 12)
+    {512, 512, 12, 4, 0},       // 0: default = AUTO: per (query, segment) group k_dscore<512,64> / k_dscore<512,256> / k_tscore<1024> by its mix of lists
     {0, 1024, 12, 4, 0},        // 1: workgroup kernel, 12288-doc tiles
     {0, 512, 12, 4, 0},         // 2: workgroup kernel,  6144-doc tiles
     {0, 256, 16, 4, 0},         // 3: workgroup kernel,  4096-doc tiles
@@ -89,6 +93,9 @@ static const VariantDesc kVariants[] = {
     {512, 512, 12, 4, 0},       // 15: k_dscore  512 slots /  64 foreign
     {512, 512, 12, 4, 0},       // 16: k_dscore  512 slots / 256 foreign
     {1024, 512, 12, 4, 0},      // 17: k_dscore 1024 slots / 128 foreign
+    {512, 512, 12, 4, 1},       // 18: doc-tile kernel k_tscore for every group, 512-doc tiles   [d == 1 marks k_tscore]
+    {1024, 512, 12, 4, 1},      // 19: k_tscore, 1024-doc tiles
+    {2048, 512, 12, 4, 1},      // 20: k_tscore, 2048-doc tiles
 };
 static constexpr uint32_t kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 static constexpr uint32_t kWaveMaxTerms = 64;
@@ -112,6 +119,16 @@ static void launch_dscore(bool and_mode, uint32_t n_items, hipStream_t st, const
         hipLaunchKernelGGL((k_dscore<HK, FB, true>), grid, block, 0, st, items, n_items, terms, segs, hits, nhits, found, K);
     else
         hipLaunchKernelGGL((k_dscore<HK, FB, false>), grid, block, 0, st, items, n_items, terms, segs, hits, nhits, found, K);
+}
+
+template <int TD>
+static void launch_tscore(bool and_mode, uint32_t n_items, hipStream_t st, const DevWItem* items, const DevTerm* terms,
+                          const DevSeg* segs, Hit* hits, uint32_t* nhits, uint64_t* found, uint32_t K) {
+    dim3 grid((n_items + 3) / 4), block(256);
+    if (and_mode)
+        hipLaunchKernelGGL((k_tscore<TD, true>), grid, block, 0, st, items, n_items, terms, segs, hits, nhits, found, K);
+    else
+        hipLaunchKernelGGL((k_tscore<TD, false>), grid, block, 0, st, items, n_items, terms, segs, hits, nhits, found, K);
 }
 
 template <int NT, int SPT, int U>
@@ -150,6 +167,16 @@ extern "C" int ns_ctx_create(int device, ns_ctx** out) {
         return rc;
     }
     ctx->stream = ctx->own_stream;
+    for (int i = 0; i < 2 && e == hipSuccess; i++) {
+        e = hipStreamCreateWithFlags(&ctx->aux_stream[i], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->join_ev[i], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        int rc = fail(nullptr, NS_E_HIP, "stream/event creation: %s", hipGetErrorString(e));
+        ns_ctx_destroy(ctx);
+        return rc;
+    }
     *out = ctx;
     return NS_OK;
 }
@@ -165,6 +192,11 @@ extern "C" void ns_ctx_destroy(ns_ctx* ctx) {
         (void)hipFree(s->d_pnorm);
         delete s;
     }
+    for (int i = 0; i < 2; i++) {
+        if (ctx->aux_stream[i]) (void)hipStreamDestroy(ctx->aux_stream[i]);
+        if (ctx->join_ev[i]) (void)hipEventDestroy(ctx->join_ev[i]);
+    }
+    if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -287,7 +319,8 @@ struct ns_batch {
     uint32_t Q = 0, K = 0, flags = 0;
     uint32_t variant = 0, tile_docs = 0, hb = 0;
     uint32_t n_items = 0;      // workgroup-kernel items (k_score)
-    uint32_t n_witems = 0;     // wave-kernel items (k_wscore)
+    uint32_t n_witems = 0;     // wave-kernel items
+    uint32_t n_class[3] = {0, 0, 0};   // auto mode: items of class S (thin foreign lists), D (dense foreign), T (very dense: doc tiles); contiguous in d_witems
     uint32_t n_bgroups = 0;    // term groups that need the boundary prepass (k_score path only)
     uint32_t n_terms = 0, n_parts = 0;
     uint64_t postings = 0;
@@ -371,7 +404,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
     }
 
     // ---- regroup term refs by (query, segment), keeping query-term order inside each group ----
-    struct HostGroup { DevGroup g; uint32_t query; uint64_t cost; bool wave; };
+    struct HostGroup { DevGroup g; uint32_t query; uint64_t cost; uint64_t cmax; bool wave; uint8_t cls; };
     std::vector<DevTerm> dterms;
     std::vector<HostGroup> groups;
     std::vector<uint32_t> qgroup_begin(n_queries + 1, 0);
@@ -407,10 +440,23 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                 t.seg = sid;
                 dterms.push_back(t);
                 hg.cost += r.count;
+                hg.cmax = std::max<uint64_t>(hg.cmax, r.count);
             }
             hg.g.term_count = (uint32_t)dterms.size() - hg.g.term_begin;
             if ((flags & NS_FLAG_AND) && hg.g.term_count > 255) return fail(ctx, NS_E_INVAL, "AND mode supports at most 255 term refs per (query, segment)");
             hg.wave = wave_path && hg.g.term_count <= kWaveMaxTerms;
+            // class of the group (auto mode only): which scoring kernel suits its mix of lists
+            //   T: very dense (>= 0.7 postings per doc over >= 2 lists): doc tiles, no hashing at all
+            //   S: one list dominates (the others hold <= 1/16 of its postings): driver stream, tiny foreign budget
+            //   D: several comparable lists: driver stream with the large foreign budget
+            {
+                const uint64_t rest = hg.cost - hg.cmax;
+                const uint32_t nd = std::max<uint32_t>(segs[sid].n_docs, 1);
+                (void)rest;
+                static const uint64_t thr10 = [] { const char* e = std::getenv("NS_TILE_THR10"); return (uint64_t)(e ? std::atoi(e) : 7); }();
+                if (hg.g.term_count >= 2 && hg.cost * 10 >= (uint64_t)nd * thr10) hg.cls = 2;
+                else hg.cls = 0;
+            }
             if (!hg.wave) {
                 hg.g.bounds_off = bounds_total;
                 bounds_total += (uint64_t)(segs[sid].n_tiles + 1) * hg.g.term_count;
@@ -434,6 +480,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
     std::vector<DevItem> items;
     std::vector<DevWItem> witems;
     std::vector<Cost> item_cost, witem_cost;
+    std::vector<uint8_t> witem_cls;
     std::vector<DevGroup> bgroups;
     std::vector<DevQuery> dq(n_queries);
     uint32_t n_rows = 0;
@@ -459,6 +506,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                     it.out_slot = n_rows++;
                     it.whole = ns == 1;
                     witem_cost.push_back({hg.cost / ns + 1, (uint32_t)witems.size()});
+                    witem_cls.push_back(hg.cls);
                     witems.push_back(it);
                 }
             } else {
@@ -498,6 +546,15 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
     std::vector<DevWItem> sorted_witems(witems.size());
     for (size_t i = 0; i < items.size(); i++) sorted_items[i] = items[item_cost[i].idx];
     for (size_t i = 0; i < witems.size(); i++) sorted_witems[i] = witems[witem_cost[i].idx];
+    uint32_t n_class[3] = {0, 0, 0};
+    if (ctx->variant == 0) {
+        // auto mode: tag very dense groups for the doc-tile body (bit 1 of DevWItem::whole)
+        for (size_t i = 0; i < witems.size(); i++) {
+            const uint8_t c = witem_cls[witem_cost[i].idx];
+            n_class[c]++;
+            if (c == 2) sorted_witems[i].whole |= 2u;
+        }
+    }
 
     ns_batch* b = new ns_batch();
     b->ctx = ctx;
@@ -505,6 +562,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
     b->variant = ctx->variant; b->tile_docs = tile_docs; b->hb = vd.hb;
     b->n_items = (uint32_t)items.size(); b->n_witems = (uint32_t)witems.size();
     b->n_bgroups = (uint32_t)bgroups.size(); b->n_terms = (uint32_t)dterms.size();
+    for (int c = 0; c < 3; c++) b->n_class[c] = n_class[c];
     b->n_parts = direct ? 0 : n_rows;
     b->postings = postings_total;
     b->direct = direct;
@@ -569,11 +627,22 @@ extern "C" int ns_batch_run(ns_batch* b, int timed) {
     Hit* sh = b->direct ? b->o_hits : b->d_part_hits;
     uint32_t* sn = b->direct ? b->o_nhits : b->d_part_nhits;
     uint64_t* sf = b->direct ? b->o_found : b->d_part_found;
-    if (b->n_witems) {
+    if (b->n_witems && b->variant == 0) {
+        // auto mode: ONE launch; each wave picks the body that suits its item (DevWItem::whole bit 1)
+        dim3 grid((b->n_witems + 3) / 4), block(256);
+        if (and_mode)
+            hipLaunchKernelGGL((k_uscore<512, 128, true>), grid, block, 0, st, b->d_witems, b->n_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K);
+        else
+            hipLaunchKernelGGL((k_uscore<512, 128, false>), grid, block, 0, st, b->d_witems, b->n_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K);
+    } else if (b->n_witems) {
         const VariantDesc wv = kVariants[b->variant];
 #define NS_W(DD, HH) launch_wscore<DD, HH>(and_mode, b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K)
 #define NS_D(HH, FF) launch_dscore<HH, FF>(and_mode, b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K)
-        if (wv.d == 0) {
+        if (wv.d == 1) {
+            if (wv.hb == 512) launch_tscore<512>(and_mode, b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K);
+            else if (wv.hb == 2048) launch_tscore<2048>(and_mode, b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K);
+            else launch_tscore<1024>(and_mode, b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K);
+        } else if (wv.d == 0) {
             switch (b->variant) {
                 case 13: NS_D(256, 64); break;
                 case 14: NS_D(1024, 256); break;

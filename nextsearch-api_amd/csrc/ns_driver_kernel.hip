@@ -29,11 +29,10 @@ namespace ns {
 // HK  table slots per wave        FB  foreign postings per super-batch (load factor FB/HK: driver lookups
 //                                    are UNSUCCESSFUL searches, whose probe length grows fast with the load)
 template <int HK, int FB, bool AND>
-__global__ void __launch_bounds__(256) k_dscore(const DevWItem* __restrict__ items, uint32_t n_items,
-                                                const DevTerm* __restrict__ terms, const DevSeg* __restrict__ segs,
-                                                Hit* __restrict__ out_hits, uint32_t* __restrict__ out_nhits,
-                                                uint64_t* __restrict__ out_found, uint32_t K) {
-    constexpr int WPB = 4;                 // independent waves per workgroup
+__device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* __restrict__ terms, const DevSeg* __restrict__ segs,
+                                            float* vals, uint32_t* keys, uint8_t* mcnt, uint64_t* cand, uint4* tab, uint32_t* aux,
+                                            Hit* __restrict__ out_hits, uint32_t* __restrict__ out_nhits,
+                                            uint64_t* __restrict__ out_found, uint32_t K, const int lane) {
     constexpr int CB = 256;                // candidate buffer entries (>= NS_MAX_K + 64, power of two)
     constexpr int FE = FB / 64;            // foreign postings per lane per super-batch
     constexpr int DE = 4;                  // driver postings per lane per round
@@ -42,26 +41,6 @@ __global__ void __launch_bounds__(256) k_dscore(const DevWItem* __restrict__ ite
     static_assert(HK == 256 || HK == 512 || HK == 1024, "HK must be 256, 512 or 1024");
     static_assert(FB % 64 == 0 && FB >= 64 && FB <= HK / 2, "FB must be a multiple of 64, at most HK/2");
 
-    __shared__ __attribute__((aligned(16))) float s_vals[WPB][HK];
-    __shared__ __attribute__((aligned(16))) uint32_t s_keys[WPB][HK];
-    __shared__ __attribute__((aligned(16))) uint8_t s_mcnt[WPB][AND ? HK : 16];   // AND: term refs that hit the slot
-    __shared__ uint64_t s_cand[WPB][CB];
-    __shared__ __attribute__((aligned(16))) uint4 s_tab[WPB][64];   // per term: {idf, qweight, first posting - excl prefix, first posting}
-    __shared__ uint32_t s_aux[WPB][64];
-
-    const int wave = threadIdx.x >> 6;
-    const int lane = threadIdx.x & 63;
-    const uint32_t item_idx = blockIdx.x * WPB + wave;
-    if (item_idx >= n_items) return;   // whole wave leaves; there is no workgroup barrier in this kernel
-
-    float* vals = s_vals[wave];
-    uint32_t* keys = s_keys[wave];
-    uint8_t* mcnt = s_mcnt[wave];
-    uint64_t* cand = s_cand[wave];
-    uint4* tab = s_tab[wave];
-    uint32_t* aux = s_aux[wave];
-
-    const DevWItem it = items[item_idx];
     const DevSeg seg = segs[it.seg];
     const uint32_t T = it.term_count;
     const gp_u2 postings = (gp_u2)seg.postings;
@@ -459,6 +438,27 @@ __global__ void __launch_bounds__(256) k_dscore(const DevWItem* __restrict__ ite
         out_nhits[it.out_slot] = n;
         out_found[it.out_slot] = (uint64_t)found;
     }
+}
+
+template <int HK, int FB, bool AND>
+__global__ void __launch_bounds__(256) k_dscore(const DevWItem* __restrict__ items, uint32_t n_items,
+                                                const DevTerm* __restrict__ terms, const DevSeg* __restrict__ segs,
+                                                Hit* __restrict__ out_hits, uint32_t* __restrict__ out_nhits,
+                                                uint64_t* __restrict__ out_found, uint32_t K) {
+    constexpr int WPB = 4;                 // independent waves per workgroup
+    __shared__ __attribute__((aligned(16))) float s_vals[WPB][HK];
+    __shared__ __attribute__((aligned(16))) uint32_t s_keys[WPB][HK];
+    __shared__ __attribute__((aligned(16))) uint8_t s_mcnt[WPB][AND ? HK : 16];   // AND: term refs that hit the slot
+    __shared__ uint64_t s_cand[WPB][256];
+    __shared__ __attribute__((aligned(16))) uint4 s_tab[WPB][64];   // per term: {idf, qweight, first posting - excl prefix, first posting}
+    __shared__ uint32_t s_aux[WPB][64];
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const uint32_t item_idx = blockIdx.x * WPB + wave;
+    if (item_idx >= n_items) return;   // whole wave leaves; there is no workgroup barrier in this kernel
+    const DevWItem it = items[item_idx];
+    dscore_body<HK, FB, AND>(it, terms, segs, s_vals[wave], s_keys[wave], s_mcnt[wave], s_cand[wave], s_tab[wave], s_aux[wave],
+                             out_hits, out_nhits, out_found, K, lane);
 }
 
 }  // namespace ns

@@ -70,7 +70,7 @@ def test_gpu_equals_oracle_and_reference_golden(name, engines):
             assert [int(b) for b in gh[qi, : gn[qi]]["score"].view(np.uint32)] == [h[2] for h in ref["hits"]]
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20])
 def test_kernel_variants_agree(variant, engines):
     """Wave-private kernel (5/6/7: 256/512/1024-entry tables) and workgroup-tile kernel (1..4)."""
     g, eng, ora = engines("mid1")
@@ -86,7 +86,7 @@ def test_kernel_variants_agree(variant, engines):
 
 
 @pytest.mark.parametrize("variant,min_items,split", [(3, 1, 0), (3, 64, 0), (3, 4096, 0), (0, 1, 1 << 30), (0, 1, 500),
-                                                      (0, 4096, 0), (5, 1, 64), (7, 100000, 1000), (12, 1, 1 << 30), (12, 1, 300), (13, 4096, 0), (14, 100000, 1000)])
+                                                      (0, 4096, 0), (5, 1, 64), (7, 100000, 1000), (12, 1, 1 << 30), (12, 1, 300), (13, 4096, 0), (14, 100000, 1000), (19, 1, 1 << 30), (18, 1, 300), (20, 4096, 0)])
 def test_doc_range_splitting_is_invisible(variant, min_items, split, engines):
     """Queries are split into doc ranges (by posting budget, and to fill the chip for small batches)
     and re-joined on the device by k_merge; the result must not depend on the split."""

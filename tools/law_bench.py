@@ -36,6 +36,17 @@ def laws():
     L["r8+r1000x2"] = ([T(8) + " " + " ".join(T(rng.randint(1000, 3000)) for _ in range(2)) for _ in range(4096)], 10)
     L["r1r2r3r4r5"] = ([" ".join(T(r) for r in (1, 2, 3, 4, 5))] * 512, 100)
     L["cfg5"] = (workloads.cfg5_queries(), 10)
+
+    def rank_of(t):
+        return workloads.WORDS.index(t) + 1 if t in workloads.WORDS else int(t[1:])
+    q5 = workloads.cfg5_queries()
+    # decomposition of cfg5: only the most frequent term of every query / queries without a hot term /
+    # queries with exactly one hot term / with two or more
+    L["cfg5_top1"] = ([min(q.split(), key=rank_of) for q in q5], 10)
+    L["cfg5_nohot"] = ([q for q in q5 if min(rank_of(t) for t in q.split()) > 32], 10)
+    L["cfg5_1hot"] = ([q for q in q5 if sum(1 for t in q.split() if rank_of(t) <= 32) == 1], 10)
+    L["cfg5_1hot_multi"] = ([q for q in q5 if sum(1 for t in q.split() if rank_of(t) <= 32) == 1 and len(q.split()) > 1], 10)
+    L["cfg5_2hot"] = ([q for q in q5 if sum(1 for t in q.split() if rank_of(t) <= 32) >= 2], 10)
     L["cfg3"] = (workloads.cfg3_queries(), 100)
     return L
 
