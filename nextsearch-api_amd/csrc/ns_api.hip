@@ -454,7 +454,9 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                 const uint32_t nd = std::max<uint32_t>(segs[sid].n_docs, 1);
                 (void)rest;
                 static const uint64_t thr10 = [] { const char* e = std::getenv("NS_TILE_THR10"); return (uint64_t)(e ? std::atoi(e) : 7); }();
+                static const uint64_t thin_ratio = [] { const char* e = std::getenv("NS_THIN_RATIO"); return (uint64_t)(e ? std::atoi(e) : 16); }();
                 if (hg.g.term_count >= 2 && hg.cost * 10 >= (uint64_t)nd * thr10) hg.cls = 2;
+                else if (thin_ratio && rest * thin_ratio <= hg.cmax) hg.cls = 1;
                 else hg.cls = 0;
             }
             if (!hg.wave) {
@@ -553,6 +555,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
             const uint8_t c = witem_cls[witem_cost[i].idx];
             n_class[c]++;
             if (c == 2) sorted_witems[i].whole |= 2u;
+            if (c == 1) sorted_witems[i].whole |= 4u;
         }
     }
 

@@ -256,8 +256,12 @@ __global__ void __launch_bounds__(256) k_uscore(const DevWItem* __restrict__ ite
     if (item_idx >= n_items) return;   // whole wave leaves; there is no workgroup barrier in this kernel
     DevWItem it = items[item_idx];
     const bool tiles = (it.whole & 2u) != 0;
+    const bool thin = (it.whole & 4u) != 0;   // the non-driver lists are thin: smallest foreign budget
     it.whole &= 1u;
-    if (tiles)
+    if (thin)
+        dscore_body<HK, 64, AND>(it, terms, segs, reinterpret_cast<float*>(s_tbl[wave]), s_tbl[wave] + HK, s_mcnt[wave], s_cand[wave],
+                                 s_tab[wave], s_aux[wave], out_hits, out_nhits, out_found, K, lane);
+    else if (tiles)
         tscore_body<2 * HK, AND>(it, terms, segs, reinterpret_cast<float*>(s_tbl[wave]), s_mcnt[wave], s_cand[wave],
                                  out_hits, out_nhits, out_found, K, lane);
     else
