@@ -445,18 +445,15 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
             hg.g.term_count = (uint32_t)dterms.size() - hg.g.term_begin;
             if ((flags & NS_FLAG_AND) && hg.g.term_count > 255) return fail(ctx, NS_E_INVAL, "AND mode supports at most 255 term refs per (query, segment)");
             hg.wave = wave_path && hg.g.term_count <= kWaveMaxTerms;
-            // class of the group (auto mode only): which scoring kernel suits its mix of lists
-            //   T: very dense (>= 0.7 postings per doc over >= 2 lists): doc tiles, no hashing at all
-            //   S: one list dominates (the others hold <= 1/16 of its postings): driver stream, tiny foreign budget
-            //   D: several comparable lists: driver stream with the large foreign budget
+            // class of the group (auto mode only): which scoring body suits its mix of lists (measured on
+            // MI355X, profiles/r01): 2 = very dense (>= 0.7 postings per doc over >= 2 lists): doc tiles;
+            // 1 = one list dominates (the others hold <= 1/16 of its postings): driver stream with the
+            // 64-posting foreign budget; 0 = driver stream with the 128-posting budget.
             {
                 const uint64_t rest = hg.cost - hg.cmax;
                 const uint32_t nd = std::max<uint32_t>(segs[sid].n_docs, 1);
-                (void)rest;
-                static const uint64_t thr10 = [] { const char* e = std::getenv("NS_TILE_THR10"); return (uint64_t)(e ? std::atoi(e) : 7); }();
-                static const uint64_t thin_ratio = [] { const char* e = std::getenv("NS_THIN_RATIO"); return (uint64_t)(e ? std::atoi(e) : 16); }();
-                if (hg.g.term_count >= 2 && hg.cost * 10 >= (uint64_t)nd * thr10) hg.cls = 2;
-                else if (thin_ratio && rest * thin_ratio <= hg.cmax) hg.cls = 1;
+                if (hg.g.term_count >= 2 && hg.cost * 10 >= (uint64_t)nd * 7) hg.cls = 2;
+                else if (rest * 16 <= hg.cmax) hg.cls = 1;
                 else hg.cls = 0;
             }
             if (!hg.wave) {
