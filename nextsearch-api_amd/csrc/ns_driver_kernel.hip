@@ -335,7 +335,21 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
                 const float sc = (d_idf * (tf * (1.2f + 1.0f))) / denom;
                 dx[j] = d_wq * sc;
             }
-            if (total > 0) {
+            // does any foreign doc of this super-batch fall into the doc range of this round?  (usually
+            // not when the driver is much denser than the foreign lists: then the lookups are skipped)
+            bool any_foreign_here = total > 0;
+            if (FB <= 64 && total > 0) {   // only worth testing for the thin-foreign class
+                const uint32_t rfirst = rdlane(ps[0].x, 0);
+                uint32_t rlast = 0;
+#pragma unroll
+                for (int j = 0; j < DE; j++)
+                    if (((n - 1u) >> 6) == (uint32_t)j) rlast = rdlane(ps[j].x, (n - 1u) & 63u);   // uniform
+                bool here = false;
+#pragma unroll
+                for (int j = 0; j < FE; j++) here = here || (fok[j] && fdoc[j] >= rfirst && fdoc[j] <= rlast);
+                any_foreign_here = __ballot(here) != 0ull;
+            }
+            if (any_foreign_here) {
                 // one lookup per posting; a hit joins the table accumulation at the driver's place in
                 // the term order (foreign terms before it are already in, those after it follow)
 #pragma unroll
