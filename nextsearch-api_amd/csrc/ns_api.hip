@@ -630,10 +630,19 @@ extern "C" int ns_batch_run(ns_batch* b, int timed) {
     if (b->n_witems && b->variant == 0) {
         // auto mode: ONE launch; each wave picks the body that suits its item (DevWItem::whole bit 1)
         dim3 grid((b->n_witems + 3) / 4), block(256);
-        if (and_mode)
-            hipLaunchKernelGGL((k_uscore<512, 128, true>), grid, block, 0, st, b->d_witems, b->n_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K);
-        else
-            hipLaunchKernelGGL((k_uscore<512, 128, false>), grid, block, 0, st, b->d_witems, b->n_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K);
+        // K <= 64: a 128-entry candidate buffer is enough (K + 64 appended per step at most) and its
+        // smaller LDS footprint admits one more workgroup per CU
+        if (b->K <= 64) {
+            if (and_mode)
+                hipLaunchKernelGGL((k_uscore<512, 128, true, 128>), grid, block, 0, st, b->d_witems, b->n_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K);
+            else
+                hipLaunchKernelGGL((k_uscore<512, 128, false, 128>), grid, block, 0, st, b->d_witems, b->n_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K);
+        } else {
+            if (and_mode)
+                hipLaunchKernelGGL((k_uscore<512, 128, true, 256>), grid, block, 0, st, b->d_witems, b->n_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K);
+            else
+                hipLaunchKernelGGL((k_uscore<512, 128, false, 256>), grid, block, 0, st, b->d_witems, b->n_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K);
+        }
     } else if (b->n_witems) {
         const VariantDesc wv = kVariants[b->variant];
 #define NS_W(DD, HH) launch_wscore<DD, HH>(and_mode, b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K)

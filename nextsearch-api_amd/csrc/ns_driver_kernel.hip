@@ -28,12 +28,12 @@ namespace ns {
 
 // HK  table slots per wave        FB  foreign postings per super-batch (load factor FB/HK: driver lookups
 //                                    are UNSUCCESSFUL searches, whose probe length grows fast with the load)
-template <int HK, int FB, bool AND>
+template <int HK, int FB, bool AND, int CB = 256>
 __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* __restrict__ terms, const DevSeg* __restrict__ segs,
                                             float* vals, uint32_t* keys, uint8_t* mcnt, uint64_t* cand, uint4* tab, uint32_t* aux,
                                             Hit* __restrict__ out_hits, uint32_t* __restrict__ out_nhits,
                                             uint64_t* __restrict__ out_found, uint32_t K, const int lane) {
-    constexpr int CB = 256;                // candidate buffer entries (>= NS_MAX_K + 64, power of two)
+    // CB: candidate buffer entries, a power of two >= K + 64 (the launcher picks 128 for K <= 64: less LDS, one more workgroup per CU)
     constexpr int FE = FB / 64;            // foreign postings per lane per super-batch
     constexpr int DE = 4;                  // driver postings per lane per round
     constexpr int LOG2HK = (HK == 256) ? 8 : (HK == 512 ? 9 : 10);

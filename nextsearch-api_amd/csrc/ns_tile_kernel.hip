@@ -22,12 +22,12 @@
 
 namespace ns {
 
-template <int TD, bool AND>
+template <int TD, bool AND, int CB = 256>
 __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* __restrict__ terms, const DevSeg* __restrict__ segs,
                                             float* vals, uint8_t* mcnt, uint64_t* cand,
                                             Hit* __restrict__ out_hits, uint32_t* __restrict__ out_nhits,
                                             uint64_t* __restrict__ out_found, uint32_t K, const int lane) {
-    constexpr int CB = 256;                // candidate buffer entries (>= NS_MAX_K + 64, power of two)
+    // CB: candidate buffer entries, a power of two >= K + 64
     constexpr int E = 4;                   // postings per lane per round
     constexpr int NG = TD / 256;           // float4 groups per lane in the tile read-back
     static_assert(TD == 512 || TD == 1024 || TD == 2048, "TD must be 512, 1024 or 2048");
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(256) k_tscore(const DevWItem* __restrict__ ite
 // item's mix of posting lists — driver stream + foreign table (dscore_body) or doc tiles for very
 // dense groups (tscore_body; DevWItem::whole bit 1).  One launch, one LDS budget: the tile body's
 // 2*HK-slot table aliases the driver body's HK values + HK keys.
-template <int HK, int FB, bool AND>
+template <int HK, int FB, bool AND, int CB>
 __global__ void __launch_bounds__(256) k_uscore(const DevWItem* __restrict__ items, uint32_t n_items,
                                                 const DevTerm* __restrict__ terms, const DevSeg* __restrict__ segs,
                                                 Hit* __restrict__ out_hits, uint32_t* __restrict__ out_nhits,
@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(256) k_uscore(const DevWItem* __restrict__ ite
     constexpr int WPB = 4;
     __shared__ __attribute__((aligned(16))) uint32_t s_tbl[WPB][2 * HK];                 // values | keys, or one 2*HK-slot tile
     __shared__ __attribute__((aligned(16))) uint8_t s_mcnt[WPB][AND ? 2 * HK : 16];
-    __shared__ uint64_t s_cand[WPB][256];
+    __shared__ uint64_t s_cand[WPB][CB];
     __shared__ __attribute__((aligned(16))) uint4 s_tab[WPB][64];
     __shared__ uint32_t s_aux[WPB][64];
     const int wave = threadIdx.x >> 6;
@@ -259,13 +259,13 @@ __global__ void __launch_bounds__(256) k_uscore(const DevWItem* __restrict__ ite
     const bool thin = (it.whole & 4u) != 0;   // the non-driver lists are thin: smallest foreign budget
     it.whole &= 1u;
     if (thin)
-        dscore_body<HK, 64, AND>(it, terms, segs, reinterpret_cast<float*>(s_tbl[wave]), s_tbl[wave] + HK, s_mcnt[wave], s_cand[wave],
+        dscore_body<HK, 64, AND, CB>(it, terms, segs, reinterpret_cast<float*>(s_tbl[wave]), s_tbl[wave] + HK, s_mcnt[wave], s_cand[wave],
                                  s_tab[wave], s_aux[wave], out_hits, out_nhits, out_found, K, lane);
     else if (tiles)
-        tscore_body<2 * HK, AND>(it, terms, segs, reinterpret_cast<float*>(s_tbl[wave]), s_mcnt[wave], s_cand[wave],
+        tscore_body<2 * HK, AND, CB>(it, terms, segs, reinterpret_cast<float*>(s_tbl[wave]), s_mcnt[wave], s_cand[wave],
                                  out_hits, out_nhits, out_found, K, lane);
     else
-        dscore_body<HK, FB, AND>(it, terms, segs, reinterpret_cast<float*>(s_tbl[wave]), s_tbl[wave] + HK, s_mcnt[wave], s_cand[wave],
+        dscore_body<HK, FB, AND, CB>(it, terms, segs, reinterpret_cast<float*>(s_tbl[wave]), s_tbl[wave] + HK, s_mcnt[wave], s_cand[wave],
                                  s_tab[wave], s_aux[wave], out_hits, out_nhits, out_found, K, lane);
 }
 
