@@ -545,15 +545,22 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
     std::vector<DevWItem> sorted_witems(witems.size());
     for (size_t i = 0; i < items.size(); i++) sorted_items[i] = items[item_cost[i].idx];
     for (size_t i = 0; i < witems.size(); i++) sorted_witems[i] = witems[witem_cost[i].idx];
-    uint32_t n_class[3] = {0, 0, 0};
+    uint32_t n_class[3] = {0, 0, 0};   // [0] = items of groups with <= 16 terms (first in d_witems), [1] = the rest
     if (ctx->variant == 0) {
-        // auto mode: tag very dense groups for the doc-tile body (bit 1 of DevWItem::whole)
+        // auto mode: tag very dense groups for the doc-tile body (bit 1 of DevWItem::whole) and groups
+        // with thin non-driver lists for the small foreign budget (bit 2); groups of <= 16 terms first
+        std::vector<DevWItem> narrow, wide;
         for (size_t i = 0; i < witems.size(); i++) {
             const uint8_t c = witem_cls[witem_cost[i].idx];
-            n_class[c]++;
-            if (c == 2) sorted_witems[i].whole |= 2u;
-            if (c == 1) sorted_witems[i].whole |= 4u;
+            DevWItem it = sorted_witems[i];
+            if (c == 2) it.whole |= 2u;
+            if (c == 1) it.whole |= 4u;
+            (it.term_count <= 16 ? narrow : wide).push_back(it);
         }
+        n_class[0] = (uint32_t)narrow.size();
+        n_class[1] = (uint32_t)wide.size();
+        sorted_witems = narrow;
+        sorted_witems.insert(sorted_witems.end(), wide.begin(), wide.end());
     }
 
     ns_batch* b = new ns_batch();
@@ -631,18 +638,24 @@ extern "C" int ns_batch_run(ns_batch* b, int timed) {
         // auto mode: ONE launch; each wave picks the body that suits its item (DevWItem::whole bit 1)
         dim3 grid((b->n_witems + 3) / 4), block(256);
         // K <= 64: a 128-entry candidate buffer is enough (K + 64 appended per step at most) and its
-        // smaller LDS footprint admits one more workgroup per CU
-        if (b->K <= 64) {
-            if (and_mode)
-                hipLaunchKernelGGL((k_uscore<512, 128, true, 128>), grid, block, 0, st, b->d_witems, b->n_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K);
-            else
-                hipLaunchKernelGGL((k_uscore<512, 128, false, 128>), grid, block, 0, st, b->d_witems, b->n_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K);
-        } else {
-            if (and_mode)
-                hipLaunchKernelGGL((k_uscore<512, 128, true, 256>), grid, block, 0, st, b->d_witems, b->n_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K);
-            else
-                hipLaunchKernelGGL((k_uscore<512, 128, false, 256>), grid, block, 0, st, b->d_witems, b->n_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K);
+        // smaller LDS footprint admits more workgroups per CU.  Groups of <= 16 terms (all but exotic
+        // queries) run in the instantiation with 16-entry term tables; the rest in the 64-entry one.
+#define NS_U(CBV, TM, N, PTR)                                                                                      \
+        {                                                                                                          \
+            dim3 g_(((N) + 3) / 4);                                                                                \
+            if (and_mode) hipLaunchKernelGGL((k_uscore<512, 128, true, CBV, TM>), g_, block, 0, st, (PTR), (N), b->d_terms, b->d_segs, sh, sn, sf, b->K); \
+            else hipLaunchKernelGGL((k_uscore<512, 128, false, CBV, TM>), g_, block, 0, st, (PTR), (N), b->d_terms, b->d_segs, sh, sn, sf, b->K);         \
         }
+        const uint32_t n_narrow = b->n_class[0], n_wide = b->n_witems - b->n_class[0];
+        (void)grid;
+        if (b->K <= 64) {
+            if (n_narrow) NS_U(128, 16, n_narrow, b->d_witems);
+            if (n_wide) NS_U(128, 64, n_wide, b->d_witems + n_narrow);
+        } else {
+            if (n_narrow) NS_U(256, 16, n_narrow, b->d_witems);
+            if (n_wide) NS_U(256, 64, n_wide, b->d_witems + n_narrow);
+        }
+#undef NS_U
     } else if (b->n_witems) {
         const VariantDesc wv = kVariants[b->variant];
 #define NS_W(DD, HH) launch_wscore<DD, HH>(and_mode, b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K)

@@ -160,7 +160,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
         for (int j = 0; j < FE; j++) { ftj[j] = 0; fslot[j] = 0; fx[j] = 0.0f; fok[j] = false; fown[j] = false; fdoc[j] = 0; }
         if (total > 0) {
             if ((uint32_t)lane < T) tab[lane] = make_uint4(idf_bits, wq_bits, base + cur - (incl - w), base + cur);
-            if (T > 8) aux[lane] = incl;
+            if (T > 8 && (uint32_t)lane < T) aux[lane] = incl;
             wave_sync();
             if (T <= 8) {
                 for (uint32_t t = 0; t + 1 < T; t++) {

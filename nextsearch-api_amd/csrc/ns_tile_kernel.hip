@@ -239,7 +239,10 @@ __global__ void __launch_bounds__(256) k_tscore(const DevWItem* __restrict__ ite
 // item's mix of posting lists — driver stream + foreign table (dscore_body) or doc tiles for very
 // dense groups (tscore_body; DevWItem::whole bit 1).  One launch, one LDS budget: the tile body's
 // 2*HK-slot table aliases the driver body's HK values + HK keys.
-template <int HK, int FB, bool AND, int CB>
+// TMAX: most terms a group may have in this instantiation (16: smaller term tables, 3 KB less LDS per
+// workgroup — with K > 64 that is the 6th workgroup per CU; 64: the general case, launched only when needed).
+// Forcing 72 VGPRs for a 7th workgroup (amdgpu_waves_per_eu) spills and measured no faster.
+template <int HK, int FB, bool AND, int CB, int TMAX>
 __global__ void __launch_bounds__(256) k_uscore(const DevWItem* __restrict__ items, uint32_t n_items,
                                                 const DevTerm* __restrict__ terms, const DevSeg* __restrict__ segs,
                                                 Hit* __restrict__ out_hits, uint32_t* __restrict__ out_nhits,
@@ -248,8 +251,8 @@ __global__ void __launch_bounds__(256) k_uscore(const DevWItem* __restrict__ ite
     __shared__ __attribute__((aligned(16))) uint32_t s_tbl[WPB][2 * HK];                 // values | keys, or one 2*HK-slot tile
     __shared__ __attribute__((aligned(16))) uint8_t s_mcnt[WPB][AND ? 2 * HK : 16];
     __shared__ uint64_t s_cand[WPB][CB];
-    __shared__ __attribute__((aligned(16))) uint4 s_tab[WPB][64];
-    __shared__ uint32_t s_aux[WPB][64];
+    __shared__ __attribute__((aligned(16))) uint4 s_tab[WPB][TMAX];
+    __shared__ uint32_t s_aux[WPB][TMAX];
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     const uint32_t item_idx = blockIdx.x * WPB + wave;

@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(256) k_wscore(const DevWItem* __restrict__ ite
         const uint32_t incl = wave_incl_scan_dpp(w);
         const uint32_t total = rdlane(incl, 63);
         if ((uint32_t)lane < T) tab[lane] = make_uint4(idf_bits, wq_bits, base + cur - (incl - w), base + cur);
-        if (T > 8) aux[lane] = incl;
+        if (T > 8 && (uint32_t)lane < T) aux[lane] = incl;
         uint32_t hi = wave_min_dpp(e);   // every posting with docId <= hi of every term is inside its window
         hi = min(hi, last_doc);
         const bool direct = (hi >= lo) && ((hi - lo) < (uint32_t)D);   // uniform

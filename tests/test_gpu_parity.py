@@ -177,7 +177,10 @@ def test_many_terms_per_query(engines):
     g, eng, ora = engines("mid1")
     q70 = " ".join(workloads.term_name(r) for r in range(3, 73))
     q130 = " ".join(workloads.term_name(1 + (r * 7) % 300) for r in range(130))
-    queries = [q70, q130, "covid " * 20]
+    q12 = " ".join(workloads.term_name(r) for r in range(2, 14))      # 9..16 terms: binary-search term lookup, narrow tables
+    q20 = " ".join(workloads.term_name(5 + 3 * r) for r in range(20))   # 17..64 terms: the wide instantiation
+    q40 = " ".join(workloads.term_name(1 + (r * 11) % 200) for r in range(40))
+    queries = [q70, q130, "covid " * 20, q12, q20, q40, q12 + " covid covid"]
     assert_same(eng.search_batch(queries, 100), ora.search_batch(queries, 100), queries, "many terms")
 
 
