@@ -126,25 +126,30 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
         }                                                                                          \
     }
 
+    // Foreign windows: sizes proportional to what is left of each foreign list (all windows span about
+    // the same doc range), at most FB postings in total; one docId probe per window (its last posting).
+    // Planned right after the cursors move, so the probes fly while the driver streams.
+    uint32_t w_n = 0, e_n = 0xFFFFFFFFu;
+#define NS_PLAN_FOREIGN()                                                                          \
+    {                                                                                              \
+        const uint32_t rem_ = end - cur;   /* 0 for the driver's lane and lanes >= T */            \
+        const uint32_t nact_ = (uint32_t)__popcll(__ballot(rem_ > 0));                             \
+        const float scale_ = (float)(FB - (int)nact_) * __builtin_amdgcn_rcpf((float)max(Rf, 1u)); \
+        uint32_t w_ = 1u + (uint32_t)((float)rem_ * scale_);                                       \
+        w_ = (w_ < rem_) ? w_ : rem_;                                                              \
+        const bool probe_ = w_ < rem_;                                                             \
+        const uint32_t pi_ = probe_ ? (base + cur + w_ - 1u) : 0u;                                 \
+        const nat_u2 pv_ = postings[pi_];   /* unconditional load of a valid index: no branch */   \
+        w_n = (rem_ > 0) ? w_ : 0u;                                                                \
+        e_n = probe_ ? pv_.x : 0xFFFFFFFFu;                                                        \
+    }
+    NS_PLAN_FOREIGN();
     wave_sync();
     for (;;) {
         ge_mode = false;
-        // ================= 1. foreign windows of this super-batch =================
-        uint32_t w = 0, e = 0xFFFFFFFFu;
-        {
-            const uint32_t rem = end - cur;   // 0 for the driver's lane and lanes >= T
-            const uint32_t nact = (uint32_t)__popcll(__ballot(rem > 0));
-            if (nact > 0) {
-                const float scale = (float)(FB - (int)nact) * __builtin_amdgcn_rcpf((float)Rf);
-                uint32_t w_ = 1u + (uint32_t)((float)rem * scale);
-                w_ = (w_ < rem) ? w_ : rem;
-                const bool probe = w_ < rem;
-                const uint32_t pi = probe ? (base + cur + w_ - 1u) : 0u;
-                const nat_u2 pv = postings[pi];   // unconditional load of a valid index: no branch
-                w = (rem > 0) ? w_ : 0u;
-                e = probe ? pv.x : 0xFFFFFFFFu;
-            }
-        }
+        // ================= 1. foreign windows of this super-batch (planned one super-batch ahead) ==========
+        const uint32_t w = w_n;
+        const uint32_t e = e_n;
         const uint32_t incl = wave_incl_scan_dpp(w);
         const uint32_t total = rdlane(incl, 63);
         uint32_t hi = wave_min_dpp(e);   // every foreign posting with docId <= hi is inside its window
@@ -232,6 +237,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
                 batch_consumed = total;
             }
             Rf = (Rf > batch_consumed) ? (Rf - batch_consumed) : 0;
+            NS_PLAN_FOREIGN();   // cursors are final: the next super-batch's probes fly from here on
             // ---- BM25 term scores (src/api_engine.cpp:477-480, operation for operation) ----
             tb_min = rdlane(ftj[0], 0);
             {
@@ -421,6 +427,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
     }
 #undef NS_FOREIGN_RMW
 #undef NS_OFFER
+#undef NS_PLAN_FOREIGN
 
     // ---- this item's top-K ----
     wave_sync();

@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(256) k_tscore(const DevWItem* __restrict__ ite
 // workgroup — with K > 64 that is the 6th workgroup per CU; 64: the general case, launched only when needed).
 // Forcing 72 VGPRs for a 7th workgroup (amdgpu_waves_per_eu) spills and measured no faster.
 template <int HK, int FB, bool AND, int CB, int TMAX>
-__global__ void __launch_bounds__(256) k_uscore(const DevWItem* __restrict__ items, uint32_t n_items,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) k_uscore(const DevWItem* __restrict__ items, uint32_t n_items,
                                                 const DevTerm* __restrict__ terms, const DevSeg* __restrict__ segs,
                                                 Hit* __restrict__ out_hits, uint32_t* __restrict__ out_nhits,
                                                 uint64_t* __restrict__ out_found, uint32_t K) {
