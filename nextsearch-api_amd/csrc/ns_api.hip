@@ -33,6 +33,7 @@ struct ns_seg {
     uint2* d_postings = nullptr;
     float* d_norm = nullptr;    // per doc
     float* d_pnorm = nullptr;   // per posting
+    bool norm_safe = false;     // every norm lies in [2^-20, 2^30]: the BM25 division may take its short form (ns_div_short)
 };
 
 struct ns_ctx {
@@ -99,7 +100,11 @@ static const VariantDesc kVariants[] = {
 };
 static constexpr uint32_t kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 static constexpr uint32_t kWaveMaxTerms = 64;
-static constexpr uint32_t kDefaultSplitPostings = 32768;
+static constexpr uint32_t kDefaultSplitPostings = 32768;   // forced variants: postings per work item
+// auto mode: work units per item (one unit = one streamed driver posting).  Every item pays for its own
+// top-K warm-up and its K-row partial result, so large K wants fewer, longer items (sweeps: profiles/r01).
+static constexpr uint32_t kSplitWorkSmallK = 98304, kSplitWorkLargeK = 262144;
+static constexpr uint64_t kWorkForeign = 8, kWorkTile = 3;
 
 template <int D, int HK>
 static void launch_wscore(bool and_mode, uint32_t n_items, hipStream_t st, const DevWItem* items, const DevTerm* terms,
@@ -240,10 +245,12 @@ extern "C" int ns_segment_upload(ns_ctx* ctx, uint32_t seg_id, uint32_t n_docs, 
 
     hipError_t e;
     uint32_t* d_len = nullptr;
-    // +16 B slack so vector loads at the tail stay inside the allocation
-    if ((e = hipMalloc((void**)&s->d_postings, nbytes + 16)) != hipSuccess) { cleanup(); return fail(ctx, NS_E_NOMEM, "hipMalloc postings (%llu B): %s", (unsigned long long)nbytes, hipGetErrorString(e)); }
+    // slack: the driver stream loads whole rounds of 256 postings (and their norms) from a list's cursor,
+    // i.e. up to 255 entries past the end of the last list
+    const size_t kPadPostings = 256;
+    if ((e = hipMalloc((void**)&s->d_postings, nbytes + kPadPostings * 8)) != hipSuccess) { cleanup(); return fail(ctx, NS_E_NOMEM, "hipMalloc postings (%llu B): %s", (unsigned long long)nbytes, hipGetErrorString(e)); }
     if ((e = hipMalloc((void**)&s->d_norm, (size_t)std::max<uint32_t>(n_docs, 1) * 4)) != hipSuccess) { cleanup(); return fail(ctx, NS_E_NOMEM, "hipMalloc norm: %s", hipGetErrorString(e)); }
-    if ((e = hipMalloc((void**)&s->d_pnorm, std::max<uint64_t>(nbytes / 2, 4))) != hipSuccess) { cleanup(); return fail(ctx, NS_E_NOMEM, "hipMalloc per-posting norms (%llu B): %s", (unsigned long long)(nbytes / 2), hipGetErrorString(e)); }
+    if ((e = hipMalloc((void**)&s->d_pnorm, nbytes / 2 + kPadPostings * 4)) != hipSuccess) { cleanup(); return fail(ctx, NS_E_NOMEM, "hipMalloc per-posting norms (%llu B): %s", (unsigned long long)(nbytes / 2), hipGetErrorString(e)); }
     if ((e = hipMalloc((void**)&d_len, (size_t)std::max<uint32_t>(n_docs, 1) * 4)) != hipSuccess) { cleanup(); return fail(ctx, NS_E_NOMEM, "hipMalloc doc_len: %s", hipGetErrorString(e)); }
 
     // pinned, double-buffered staging: host memcpy of chunk i+1 overlaps the DMA of chunk i
@@ -273,7 +280,9 @@ extern "C" int ns_segment_upload(ns_ctx* ctx, uint32_t seg_id, uint32_t n_docs, 
     };
     e = hipSuccess;
     if (ok) {
-        if (nbytes) e = stage(s->d_postings, postings, nbytes);
+        e = hipMemsetAsync((char*)s->d_postings + nbytes, 0xFF, kPadPostings * 8, ctx->stream);   // docId ~0: never taken
+        if (e == hipSuccess) e = hipMemsetAsync((char*)s->d_pnorm + nbytes / 2, 0, kPadPostings * 4, ctx->stream);
+        if (e == hipSuccess && nbytes) e = stage(s->d_postings, postings, nbytes);
         if (e == hipSuccess && n_docs) e = stage(d_len, doc_len, (size_t)n_docs * 4);
         if (e == hipSuccess && n_docs) {
             hipLaunchKernelGGL(k_norm, dim3((n_docs + 255) / 256), dim3(256), 0, ctx->stream, d_len, s->d_norm, n_docs, avgdl);
@@ -294,6 +303,15 @@ extern "C" int ns_segment_upload(ns_ctx* ctx, uint32_t seg_id, uint32_t n_docs, 
     if (!ok) { cleanup(); return fail(ctx, NS_E_NOMEM, "pinned staging allocation failed"); }
     if (e != hipSuccess) { cleanup(); return fail(ctx, NS_E_HIP, "segment upload: %s", hipGetErrorString(e)); }
 
+    {
+        // norms are monotone in doc_len (k_norm's expression, evaluated here the same way): the extremes bound them all
+        uint32_t dl_min = 0xFFFFFFFFu, dl_max = 0;
+        for (uint32_t i = 0; i < n_docs; i++) { dl_min = std::min(dl_min, doc_len[i]); dl_max = std::max(dl_max, doc_len[i]); }
+        auto norm_of = [&](uint32_t dl) { return 1.2f * ((1.0f - 0.75f) + 0.75f * ((float)dl / avgdl)); };
+        const float lo_ok = 9.5367431640625e-07f /* 2^-20 */, hi_ok = 1073741824.0f /* 2^30 */;
+        s->norm_safe = n_docs > 0 && std::isfinite(avgdl) && avgdl > 0.0f && norm_of(dl_min) >= lo_ok && norm_of(dl_min) <= hi_ok &&
+                       norm_of(dl_max) >= lo_ok && norm_of(dl_max) <= hi_ok;
+    }
     if (ctx->segs.size() <= seg_id) ctx->segs.resize(seg_id + 1, nullptr);
     ctx->segs[seg_id] = s;
     if (out) *out = s;
@@ -404,7 +422,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
     }
 
     // ---- regroup term refs by (query, segment), keeping query-term order inside each group ----
-    struct HostGroup { DevGroup g; uint32_t query; uint64_t cost; uint64_t cmax; bool wave; uint8_t cls; };
+    struct HostGroup { DevGroup g; uint32_t query; uint64_t cost; uint64_t cmax; uint64_t work; bool wave; uint8_t cls; bool fast_div; };
     std::vector<DevTerm> dterms;
     std::vector<HostGroup> groups;
     std::vector<uint32_t> qgroup_begin(n_queries + 1, 0);
@@ -426,6 +444,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
         std::sort(seg_ids.begin(), seg_ids.end());   // segments in manifest (id) order, api_engine.cpp:441
         for (uint32_t sid : seg_ids) {
             HostGroup hg{};
+            hg.fast_div = ctx->segs[sid]->norm_safe;
             hg.g.term_begin = (uint32_t)dterms.size();
             hg.g.seg = sid;
             hg.query = q;
@@ -441,6 +460,8 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                 dterms.push_back(t);
                 hg.cost += r.count;
                 hg.cmax = std::max<uint64_t>(hg.cmax, r.count);
+                // 2^-30 <= idf <= 2^30 (and finite): see ns_div_short
+                if (!(r.idf >= 9.313225746154785e-10f && r.idf <= 1073741824.0f)) hg.fast_div = false;
             }
             hg.g.term_count = (uint32_t)dterms.size() - hg.g.term_begin;
             if ((flags & NS_FLAG_AND) && hg.g.term_count > 255) return fail(ctx, NS_E_INVAL, "AND mode supports at most 255 term refs per (query, segment)");
@@ -455,6 +476,9 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                 if (hg.g.term_count >= 2 && hg.cost * 10 >= (uint64_t)nd * 7) hg.cls = 2;
                 else if (rest * 16 <= hg.cmax) hg.cls = 1;
                 else hg.cls = 0;
+                // work estimate in units of one streamed driver posting (measured, profiles/r01): a foreign
+                // posting (claim, accumulate, read back) costs ~10x, a doc-tile posting ~3x
+                hg.work = (ctx->variant != 0) ? hg.cost : (hg.cls == 2 ? hg.cost * kWorkTile : hg.cmax + rest * kWorkForeign);
             }
             if (!hg.wave) {
                 hg.g.bounds_off = bounds_total;
@@ -468,10 +492,11 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
     if (bounds_total >= (1ull << 32)) return fail(ctx, NS_E_INVAL, "batch too large: %llu boundary entries; split the batch", (unsigned long long)bounds_total);
 
     // ---- work items.  A group is split into doc ranges (a) so that no single worker carries more
-    // than ~split_postings postings (the longest item bounds the batch's tail), and (b) so that a
-    // small batch still fills the chip.  Partial rows of one query are contiguous; k_merge joins them.
+    // than ~split_postings units of estimated work (the longest item bounds the batch's tail; launch
+    // order is longest-estimated-work first), and (b) so that a small batch still fills the chip.  Partial rows of one query are contiguous; k_merge joins them.
     const uint32_t min_items = ctx->min_items ? ctx->min_items : (uint32_t)std::max(ctx->n_cus, 1) * 8u;
-    const uint64_t split_postings = ctx->split_postings ? ctx->split_postings : kDefaultSplitPostings;
+    const uint64_t split_postings = ctx->split_postings ? ctx->split_postings
+                                    : (ctx->variant != 0 ? kDefaultSplitPostings : (k <= 32 ? kSplitWorkSmallK : kSplitWorkLargeK));
     const uint32_t G = (uint32_t)groups.size();
     uint32_t chunks_per_group = 1;
     if (G > 0 && G < min_items) chunks_per_group = (min_items + G - 1) / G;
@@ -491,7 +516,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
             const DevSeg& sg = segs[hg.g.seg];
             if (sg.n_docs == 0) continue;   // empty segment: nothing to score
             if (hg.wave) {
-                uint64_t want = std::max<uint64_t>((hg.cost + split_postings - 1) / split_postings, chunks_per_group);
+                uint64_t want = std::max<uint64_t>((hg.work + split_postings - 1) / split_postings, chunks_per_group);
                 uint32_t ns = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want, 1), std::min<uint32_t>(sg.n_docs, 4096));
                 for (uint32_t i = 0; i < ns; i++) {
                     DevWItem it{};
@@ -503,8 +528,8 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                     it.doc_hi = (uint32_t)((uint64_t)sg.n_docs * (i + 1) / ns);
                     if (it.doc_hi <= it.doc_lo) continue;
                     it.out_slot = n_rows++;
-                    it.whole = ns == 1;
-                    witem_cost.push_back({hg.cost / ns + 1, (uint32_t)witems.size()});
+                    it.whole = (ns == 1 ? 1u : 0u) | (hg.fast_div ? 8u : 0u);
+                    witem_cost.push_back({hg.work / ns + 1, (uint32_t)witems.size()});
                     witem_cls.push_back(hg.cls);
                     witems.push_back(it);
                 }

@@ -3,13 +3,15 @@
 // One WAVE scores one work item = one (query, segment) term group (<= 64 terms) over a doc range.
 // The term with the most postings in the range is the item's DRIVER; all other terms are FOREIGN.
 // The wave advances in super-batches [lo, hi]:
-//   1. plan windows over the FOREIGN terms only (<= HK/2 postings in total, proportional to what is
+//   1. plan windows over the FOREIGN terms only (<= FB postings in total, proportional to what is
 //      left of each list), probe each window's last docId: hi = min of those (or the end of the range)
-//   2. load the foreign postings (flat, coalesced), BM25 term scores, claim a slot per distinct docId
-//      in an open-addressing table (no LDS atomics: store / read back), elect one owner per slot,
-//      accumulate the foreign terms that come BEFORE the driver in query order (read-add-write per term)
-//   3. stream the driver's postings with docId <= hi in rounds of 256: BM25 term score, ONE table
-//      lookup per posting; a miss (the common case) means no other term has that doc: the doc's score
+//   2. load the foreign postings (flat, coalesced), BM25 term scores, claim an entry per distinct docId
+//      in a BUCKETED table (NB buckets of 4 entries = one ds_read_b128; bucket = low docId bits; entry =
+//      (docId - lo) << 8 | index of the posting that owns the doc's accumulator; no LDS atomics: store /
+//      read back), accumulate the foreign terms that come BEFORE the driver in query order
+//      (read-add-write per term on the owner's accumulator)
+//   3. stream the driver's postings with docId <= hi in rounds of 256: BM25 term score, ONE bucket
+//      read per posting; a miss (the common case) means no other term has that doc: the doc's score
 //      is 0.0f + w*s == w*s exactly, it never touches the table; a hit joins the table accumulation
 //   4. accumulate the foreign terms that come AFTER the driver
 //   5. owners read the final scores back, count `found`, offer candidates, reset their slots
@@ -26,23 +28,32 @@
 
 namespace ns {
 
-// HK  table slots per wave        FB  foreign postings per super-batch (load factor FB/HK: driver lookups
-//                                    are UNSUCCESSFUL searches, whose probe length grows fast with the load)
-template <int HK, int FB, bool AND, int CB = 256>
+// NB  buckets of 4 entries per wave   FB  foreign postings per super-batch (<= 256: the owner index has 8 bits).
+// A driver lookup reads ONE bucket and stops unless the bucket is full and holds no match: with FB/NB <= 0.5
+// a full bucket is a 0.2% event, so practically every lookup is a single ds_read_b128 for all 64 lanes.
+template <int NB, int FB, bool AND, int CB = 256>
 __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* __restrict__ terms, const DevSeg* __restrict__ segs,
-                                            float* vals, uint32_t* keys, uint8_t* mcnt, uint64_t* cand, uint4* tab, uint32_t* aux,
+                                            uint32_t* ent, float* vals, uint8_t* mcnt, uint64_t* cand, uint4* tab, uint32_t* aux,
                                             Hit* __restrict__ out_hits, uint32_t* __restrict__ out_nhits,
                                             uint64_t* __restrict__ out_found, uint32_t K, const int lane) {
     // CB: candidate buffer entries, a power of two >= K + 64 (the launcher picks 128 for K <= 64: less LDS, one more workgroup per CU)
     constexpr int FE = FB / 64;            // foreign postings per lane per super-batch
     constexpr int DE = 4;                  // driver postings per lane per round
-    constexpr int LOG2HK = (HK == 256) ? 8 : (HK == 512 ? 9 : 10);
-    constexpr uint32_t EMPTY = 0xFFFFFFFFu;
-    static_assert(HK == 256 || HK == 512 || HK == 1024, "HK must be 256, 512 or 1024");
-    static_assert(FB % 64 == 0 && FB >= 64 && FB <= HK / 2, "FB must be a multiple of 64, at most HK/2");
+    // entry = (0x8000 | tag) << 16 | home bucket << 8 | owner index; tag = the 15 docId bits above the bucket
+    // bits; 0 = empty.  Tag + home bucket pin the low LOG2NB + 15 docId bits, wherever the entry ended up
+    // (a full bucket spills into the next one): exact as long as a super-batch spans fewer docs than that.
+    constexpr uint32_t EMPTY = 0u;
+    constexpr int LOG2NB = (NB == 64) ? 6 : (NB == 128 ? 7 : 8);
+    constexpr uint32_t MAXSPAN = (1u << (LOG2NB + 15)) - 1u;   // docs per super-batch - 1
+#define NS_TAG(doc) (0x8000u | (((doc) >> LOG2NB) & 0x7FFFu))
+#define NS_IDENT(doc) ((NS_TAG(doc) << 16) | (((doc) & (uint32_t)(NB - 1)) << 8))
+    static_assert(NB == 64 || NB == 128 || NB == 256, "NB must be 64, 128 or 256");
+    static_assert(FB % 64 == 0 && FB >= 64 && FB <= 256 && FB <= 2 * NB, "FB must be a multiple of 64, at most 256 and 2*NB");
+    uint4* ent4 = reinterpret_cast<uint4*>(ent);
 
     const DevSeg seg = segs[it.seg];
     const uint32_t T = it.term_count;
+    const bool fast_div = (__builtin_amdgcn_readfirstlane((int)it.whole) & 8) != 0;   // host: every idf and norm of this item is in the range where v_div_scale/v_div_fixup are the identity
     const gp_u2 postings = (gp_u2)seg.postings;
     const gp_f32 pnorm = (gp_f32)seg.pnorm;
 
@@ -50,14 +61,13 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
         const float4 sent4 = make_float4(__uint_as_float(kSentinelBits), __uint_as_float(kSentinelBits),
                                          __uint_as_float(kSentinelBits), __uint_as_float(kSentinelBits));
         const uint4 empty4 = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
-        float4* v4 = reinterpret_cast<float4*>(vals);
-        uint4* k4 = reinterpret_cast<uint4*>(keys);
+        (void)sent4;
 #pragma unroll
-        for (int g = 0; g < HK / 256; g++) { v4[g * 64 + lane] = sent4; k4[g * 64 + lane] = empty4; }
-        if (AND) {
-            uint32_t* m32 = reinterpret_cast<uint32_t*>(mcnt);
+        for (int g = 0; g < NB / 64; g++) ent4[g * 64 + lane] = empty4;
 #pragma unroll
-            for (int g = 0; g < HK / 256; g++) m32[g * 64 + lane] = 0;
+        for (int g = 0; g < FB / 64; g++) {
+            vals[g * 64 + lane] = __uint_as_float(kSentinelBits);
+            if (AND) mcnt[g * 64 + lane] = 0;
         }
     }
 
@@ -69,12 +79,15 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
         idf_bits = __float_as_uint(tm.idf);
         wq_bits = __float_as_uint(tm.weight);
         end = tm.count;
-        if (!it.whole) {
+        if (!(it.whole & 1u)) {
             const uint2* lst = seg.postings + tm.list_off;
             cur = list_lower_bound(lst, tm.count, it.doc_lo);
             end = list_lower_bound(lst, tm.count, it.doc_hi);
             if (end < cur) end = cur;
         }
+        cur += base;   // absolute posting indices from here on
+        end += base;
+        tab[lane] = make_uint4(idf_bits, wq_bits, 0u, 0u);   // .z/.w: this super-batch's window, written below
     }
     // ---- the driver: the term with the most postings in this item's range (fixed for the item) ----
     uint32_t dl;
@@ -84,7 +97,6 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
         dl = (uint32_t)__builtin_ctzll(__ballot(remv == mx && (uint32_t)lane < T) | (1ull << 63));
         if (dl >= T) dl = 0;
     }
-    const uint32_t d_base = rdlane(base, dl);
     uint32_t d_cur = rdlane(cur, dl);
     const uint32_t d_end = rdlane(end, dl);
     const float d_idf = __uint_as_float(rdlane(idf_bits, dl));
@@ -104,7 +116,8 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
     const uint32_t last_doc = it.doc_hi - 1;   // host guarantees doc_hi > doc_lo and doc_hi <= n_docs
     float theta = -__builtin_inff();
     uint32_t ncand = 0;
-    uint32_t found_lane = 0;
+    uint32_t found_lane = 0;   // per-lane part of `found` (foreign docs)
+    uint32_t found_s = 0;      // wave-uniform part (private driver postings)
     bool ge_mode = false;   // a shrink happened inside the current super-batch: ties with theta may still win on docId
 
     // offer (score, doc) of the lanes where `cond` holds to the candidate buffer
@@ -126,6 +139,23 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
         }                                                                                          \
     }
 
+    // the same with the condition given as a lane mask in SGPRs
+#define NS_OFFER_M(condm, scorev, docv)                                                            \
+    {                                                                                              \
+        uint64_t mask_ = (condm) & (ge_mode ? wballot((scorev) >= theta) : wballot((scorev) > theta)); \
+        if (mask_ != 0ull) {                                                                       \
+            uint32_t n_ = (uint32_t)__popcll(mask_);                                               \
+            if (ncand + n_ > (uint32_t)CB) {                                                       \
+                ncand = wave_shrink(cand, ncand, theta, K, lane);                                  \
+                ge_mode = true;                                                                    \
+                mask_ = (condm) & wballot((scorev) >= theta);                                      \
+                n_ = (uint32_t)__popcll(mask_);                                                    \
+            }                                                                                      \
+            if (__builtin_amdgcn_inverse_ballot_w64(mask_)) cand[ncand + lanes_below(mask_)] = make_key((scorev), (docv)); \
+            ncand += n_;                                                                           \
+        }                                                                                          \
+    }
+
     // Foreign windows: sizes proportional to what is left of each foreign list (all windows span about
     // the same doc range), at most FB postings in total; one docId probe per window (its last posting).
     // Planned right after the cursors move, so the probes fly while the driver streams.
@@ -138,7 +168,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
         uint32_t w_ = 1u + (uint32_t)((float)rem_ * scale_);                                       \
         w_ = (w_ < rem_) ? w_ : rem_;                                                              \
         const bool probe_ = w_ < rem_;                                                             \
-        const uint32_t pi_ = probe_ ? (base + cur + w_ - 1u) : 0u;                                 \
+        const uint32_t pi_ = probe_ ? (cur + w_ - 1u) : 0u;                                        \
         const nat_u2 pv_ = postings[pi_];   /* unconditional load of a valid index: no branch */   \
         w_n = (rem_ > 0) ? w_ : 0u;                                                                \
         e_n = probe_ ? pv_.x : 0xFFFFFFFFu;                                                        \
@@ -153,18 +183,21 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
         const uint32_t incl = wave_incl_scan_dpp(w);
         const uint32_t total = rdlane(incl, 63);
         uint32_t hi = wave_min_dpp(e);   // every foreign posting with docId <= hi is inside its window
-        hi = min(hi, last_doc);
+        // a super-batch spans at most 2^24 - 1 docs (the entry keeps docId - lo in 24 bits)
+        const uint32_t span_hi = (last_doc - lo > MAXSPAN) ? (lo + MAXSPAN) : last_doc;
+        const bool span_clamped = hi > span_hi && span_hi != last_doc;
+        hi = min(hi, span_hi);
 
         // ================= 2. foreign postings -> table =================
-        uint32_t ftj[FE], fslot[FE];
+        uint32_t ftj[FE];     // term of the lane's j-th foreign posting; after the claim: term | owner's posting number << 6 | entry index << 14
         float fx[FE];
-        bool fok[FE], fown[FE];
+        bool fok[FE], fmine[FE];
         uint32_t fdoc[FE];
         uint32_t tb_min = 0, tb_max = 0;
 #pragma unroll
-        for (int j = 0; j < FE; j++) { ftj[j] = 0; fslot[j] = 0; fx[j] = 0.0f; fok[j] = false; fown[j] = false; fdoc[j] = 0; }
+        for (int j = 0; j < FE; j++) { ftj[j] = 0; fx[j] = 0.0f; fok[j] = false; fmine[j] = false; fdoc[j] = 0; }
         if (total > 0) {
-            if ((uint32_t)lane < T) tab[lane] = make_uint4(idf_bits, wq_bits, base + cur - (incl - w), base + cur);
+            if ((uint32_t)lane < T) reinterpret_cast<uint2*>(tab + lane)[1] = make_uint2(cur - (incl - w), cur);
             if (T > 8 && (uint32_t)lane < T) aux[lane] = incl;
             wave_sync();
             if (T <= 8) {
@@ -202,7 +235,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
             // ---- cursors: the first NOT-taken posting of a window publishes the new cursor ----
             uint32_t batch_consumed;
             {
-                if ((uint32_t)lane < T) aux[lane] = base + cur + w;   // default: whole window consumed
+                if ((uint32_t)lane < T) aux[lane] = cur + w;   // default: whole window consumed
                 wave_sync();
                 unsigned long long prev_last = 1ull;
 #pragma unroll
@@ -220,7 +253,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
                 wave_sync();
                 uint32_t c = 0;
                 if ((uint32_t)lane < T && (uint32_t)lane != dl) {
-                    const uint32_t ncur = aux[lane] - base;
+                    const uint32_t ncur = aux[lane];
                     c = ncur - cur;
                     cur = ncur;
                 }
@@ -232,7 +265,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
                 c += dpp_mov<0x143, 0xc>(0u, c);
                 batch_consumed = rdlane(c, 63);
             }
-            if (batch_consumed == 0) {   // only with corrupt lists (docIds beyond the range): skip the windows
+            if (batch_consumed == 0 && !span_clamped) {   // only with corrupt lists (docIds beyond the range): skip the windows
                 if ((uint32_t)lane != dl) { cur += w; if (cur > end) cur = end; }
                 batch_consumed = total;
             }
@@ -248,48 +281,70 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
                     if ((lastp >> 6) == (uint32_t)j) tl = rdlane(ftj[j], lastp & 63u);   // uniform
                 tb_max = tl;
             }
+            {
+                float num[FE], den[FE], wqv[FE];
 #pragma unroll
-            for (int j = 0; j < FE; j++) {
-                const uint4 ent = tab[ftj[j]];
-                const float tf = (float)pst[j].y;
-                const float denom = tf + nrm[j];
-                const float sc = (__uint_as_float(ent.x) * (tf * (1.2f + 1.0f))) / denom;
-                fx[j] = __uint_as_float(ent.y) * sc;
+                for (int j = 0; j < FE; j++) {
+                    const uint4 te = tab[ftj[j]];
+                    const float tf = (float)pst[j].y;
+                    den[j] = tf + nrm[j];
+                    num[j] = __uint_as_float(te.x) * (tf * (1.2f + 1.0f));
+                    wqv[j] = __uint_as_float(te.y);
+                }
+                ns_div_n<FE>(fx, num, den, fast_div);
+#pragma unroll
+                for (int j = 0; j < FE; j++) fx[j] = wqv[j] * fx[j];
             }
-            // ---- claim one slot per distinct docId WITHOUT LDS atomics (integer and float LDS atomics
-            //      are serialised per lane on gfx950): read the key; if the slot is free store our docId
-            //      and read it back — a wave's LDS operations execute in order, so exactly one of the
-            //      colliding docIds survives and everybody else moves on; equal docIds agree. ----
+            // ---- claim one entry per distinct docId WITHOUT LDS atomics (integer and float LDS atomics
+            //      are serialised per lane on gfx950): read the bucket; a matching entry names the doc's
+            //      owner; otherwise store our entry at the first free position and read it back — a wave's
+            //      LDS operations execute in order, so exactly one of the colliding entries survives;
+            //      equal docIds agree on the survivor (the OWNER of the doc's accumulator), everybody
+            //      else retries on the same bucket (or the next one when it is full). ----
 #pragma unroll
             for (int j = 0; j < FE; j++) {
                 if ((uint32_t)(j * 64) >= total) continue;   // uniform
-                uint32_t sl = (fdoc[j] * 2654435761u) >> (32 - LOG2HK);
+                const uint32_t me = (uint32_t)(j * 64 + lane);
+                const uint32_t mine = NS_IDENT(fdoc[j]) | me;
+                uint32_t b = fdoc[j] & (uint32_t)(NB - 1);
                 bool pending = fok[j];
-                for (int round = 0; round < HK; round++) {
+                uint32_t slot = 0, own = 0;
+                bool scan = pending;   // lanes that have to read their (new) bucket
+                uint32_t pos = 0;
+                for (int round = 0; round < 8 * NB; round++) {
                     if (__ballot(pending) == 0ull) break;
-                    uint32_t k = EMPTY;
-                    if (pending) k = keys[sl];
-                    if (pending && k == EMPTY) keys[sl] = fdoc[j];
+                    if (__ballot(scan) != 0ull) {
+                        if (scan) {
+                            const uint4 q = ent4[b];
+                            uint32_t m = 0;   // the entry of the same docId, if any
+                            m = ((q.x ^ mine) < 256u) ? q.x : m;
+                            m = ((q.y ^ mine) < 256u) ? q.y : m;
+                            m = ((q.z ^ mine) < 256u) ? q.z : m;
+                            m = ((q.w ^ mine) < 256u) ? q.w : m;
+                            pos = (q.x >> 31) + (q.y >> 31) + (q.z >> 31) + (q.w >> 31);   // entries fill a bucket in order
+                            if (m != 0) { own = m & 255u; pending = false; }
+                            scan = false;
+                        }
+                    }
+                    // Every lane that stores into a bucket in this step saw the same fill level, so they all
+                    // target the same position and exactly one entry lands: the losers' next free position
+                    // is pos + 1, no need to read the bucket again (same docIds move in lockstep and agree).
+                    const bool try_store = pending && pos < 4;
+                    if (try_store) ent[b * 4 + pos] = mine;
                     wave_sync();
-                    if (pending && k == EMPTY) k = keys[sl];
-                    if (pending && k == fdoc[j]) pending = false;
-                    if (pending) sl = (sl + 1) & (HK - 1);
+                    if (try_store) {
+                        const uint32_t back = ent[b * 4 + pos];
+                        if ((back ^ mine) < 256u) { slot = b * 4 + pos; own = back & 255u; pending = false; }
+                        else pos++;
+                    } else if (pending) {
+                        b = (b + 1) & (uint32_t)(NB - 1);   // full bucket without a match
+                        scan = true;
+                    }
+                    wave_sync();
                 }
-                fslot[j] = sl;
+                fmine[j] = fok[j] && own == me;
+                ftj[j] |= (own << 6) | (slot << 14);
             }
-            // ---- elect ONE owner per slot (several terms may hold the same doc): last store wins ----
-#pragma unroll
-            for (int j = 0; j < FE; j++)
-                if (fok[j]) vals[fslot[j]] = __uint_as_float((uint32_t)(j * 64 + lane));
-            wave_sync();
-#pragma unroll
-            for (int j = 0; j < FE; j++)
-                if (fok[j]) fown[j] = __float_as_uint(vals[fslot[j]]) == (uint32_t)(j * 64 + lane);
-            wave_sync();
-#pragma unroll
-            for (int j = 0; j < FE; j++)
-                if (fown[j]) vals[fslot[j]] = __uint_as_float(kSentinelBits);
-            wave_sync();
         }
 
         // term-ordered accumulation of foreign terms in [ta, tb] (read-add-write per term; docIds are
@@ -300,12 +355,13 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
             float old_[FE];                                                                        \
             _Pragma("unroll") for (int j = 0; j < FE; j++) {                                       \
                 old_[j] = 0.0f;                                                                    \
-                if (fok[j] && ftj[j] == tt) old_[j] = vals[fslot[j]];                              \
+                if (fok[j] && (ftj[j] & 63u) == tt) old_[j] = vals[(ftj[j] >> 6) & 255u];          \
             }                                                                                      \
             _Pragma("unroll") for (int j = 0; j < FE; j++) {                                       \
-                if (fok[j] && ftj[j] == tt) {                                                      \
-                    vals[fslot[j]] = old_[j] + fx[j];                                              \
-                    if (AND) mcnt[fslot[j]] = (uint8_t)(mcnt[fslot[j]] + 1);                       \
+                if (fok[j] && (ftj[j] & 63u) == tt) {                                              \
+                    const uint32_t o_ = (ftj[j] >> 6) & 255u;                                      \
+                    vals[o_] = old_[j] + fx[j];                                                    \
+                    if (AND) mcnt[o_] = (uint8_t)(mcnt[o_] + 1);                                   \
                 }                                                                                  \
             }                                                                                      \
             wave_sync();                                                                           \
@@ -313,33 +369,45 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
         if (total > 0 && tb_min < dl) { NS_FOREIGN_RMW(tb_min, min(tb_max, dl - 1)); }
 
         // ================= 3. stream the driver's postings with docId <= hi =================
+        // Lane predicates of this section live in SGPR pairs (ballot masks combined with scalar logic);
+        // the loads use a scalar base + a fixed lane offset (they may run up to 255 postings past the
+        // end of the list: the device buffers are padded), so the only vector work per posting is the
+        // docId compare, the BM25 term score and the bucket probe.
         bool driver_progress = false;
         for (;;) {
             const uint32_t remd = d_end - d_cur;
             if (remd == 0) break;
             const uint32_t n = min(remd, (uint32_t)(DE * 64));
+            const gp_u2 sp = postings + d_cur;
+            const gp_f32 np = pnorm + d_cur;
             nat_u2 ps[DE];
             float nr[DE];
 #pragma unroll
             for (int j = 0; j < DE; j++) {
-                const uint32_t p = (uint32_t)(j * 64 + lane);
-                const uint32_t idx = d_base + d_cur + ((p < n) ? p : 0u);
-                ps[j] = postings[idx];
-                nr[j] = pnorm[idx];
-                ps[j].x = (p < n) ? ps[j].x : 0xFFFFFFFFu;
+                ps[j] = sp[j * 64 + lane];
+                nr[j] = np[j * 64 + lane];
             }
             uint32_t cnt = 0;
             float dx[DE];
-            bool dok[DE];
+            uint64_t dokm[DE];   // postings of this round that belong to the super-batch and are still private
 #pragma unroll
             for (int j = 0; j < DE; j++) {
-                const bool take = ps[j].x <= hi;
-                cnt += (uint32_t)__popcll(__ballot(take));
-                dok[j] = take && (ps[j].x >= lo);
-                const float tf = (float)ps[j].y;
-                const float denom = tf + nr[j];
-                const float sc = (d_idf * (tf * (1.2f + 1.0f))) / denom;
-                dx[j] = d_wq * sc;
+                const uint32_t left = (n > (uint32_t)(j * 64)) ? (n - (uint32_t)(j * 64)) : 0u;   // scalar
+                const uint64_t nmask = (left >= 64u) ? ~0ull : ((1ull << left) - 1ull);
+                dokm[j] = wballot(ps[j].x <= hi) & nmask;
+                cnt += (uint32_t)__popcll(dokm[j]);
+            }
+            {   // src/api_engine.cpp:477-480, operation for operation
+                float num[DE], den[DE];
+#pragma unroll
+                for (int j = 0; j < DE; j++) {
+                    const float tf = (float)ps[j].y;
+                    den[j] = tf + nr[j];
+                    num[j] = d_idf * (tf * (1.2f + 1.0f));
+                }
+                ns_div_n<DE>(dx, num, den, fast_div);
+#pragma unroll
+                for (int j = 0; j < DE; j++) dx[j] = d_wq * dx[j];
             }
             // does any foreign doc of this super-batch fall into the doc range of this round?  (usually
             // not when the driver is much denser than the foreign lists: then the lookups are skipped)
@@ -353,38 +421,55 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
                 bool here = false;
 #pragma unroll
                 for (int j = 0; j < FE; j++) here = here || (fok[j] && fdoc[j] >= rfirst && fdoc[j] <= rlast);
-                any_foreign_here = __ballot(here) != 0ull;
+                any_foreign_here = wballot(here) != 0ull;
             }
             if (any_foreign_here) {
-                // one lookup per posting; a hit joins the table accumulation at the driver's place in
+                // one bucket read per posting; a hit joins the table accumulation at the driver's place in
                 // the term order (foreign terms before it are already in, those after it follow)
 #pragma unroll
                 for (int j = 0; j < DE; j++) {
                     if ((uint32_t)(j * 64) >= n) continue;   // uniform
-                    uint32_t sl = (ps[j].x * 2654435761u) >> (32 - LOG2HK);
-                    bool pending = dok[j];
-                    bool hit = false;
-                    for (int round = 0; round < HK; round++) {
-                        if (__ballot(pending) == 0ull) break;
-                        uint32_t k = EMPTY;
-                        if (pending) k = keys[sl];
-                        if (pending && k == ps[j].x) { hit = true; pending = false; }
-                        if (pending && k == EMPTY) pending = false;
-                        if (pending) sl = (sl + 1) & (HK - 1);
-                    }
-                    if (hit) {
-                        vals[sl] = vals[sl] + dx[j];
-                        if (AND) mcnt[sl] = (uint8_t)(mcnt[sl] + 1);
-                        dok[j] = false;   // scored through the table's owner
+                    const uint32_t tag = NS_TAG(ps[j].x);
+                    uint32_t b = ps[j].x & (uint32_t)(NB - 1);
+                    uint4 q = ent4[b];
+                    // first the 16-bit tags (one compare per entry); a tag match is verified below
+                    const uint64_t cm = wballot((q.x >> 16) == tag) | wballot((q.y >> 16) == tag) |
+                                        wballot((q.z >> 16) == tag) | wballot((q.w >> 16) == tag);
+                    // full bucket without a tag match: the doc may sit in the next bucket (a 0.2% event per lane)
+                    const uint64_t go = dokm[j] & (cm | wballot(q.w != EMPTY));
+                    if (go != 0ull) {
+                        const uint32_t ident = NS_IDENT(ps[j].x);
+                        uint32_t m = 0;
+                        bool more = __builtin_amdgcn_inverse_ballot_w64(go);
+                        while (wballot(more) != 0ull) {
+                            if (more) {
+                                m = ((q.x ^ ident) < 256u) ? q.x : m;
+                                m = ((q.y ^ ident) < 256u) ? q.y : m;
+                                m = ((q.z ^ ident) < 256u) ? q.z : m;
+                                m = ((q.w ^ ident) < 256u) ? q.w : m;
+                                more = m == 0 && q.w != EMPTY;
+                                if (more) { b = (b + 1) & (uint32_t)(NB - 1); q = ent4[b]; }
+                            }
+                        }
+                        const uint64_t hitm = wballot(m != 0);   // only lanes of `go` ever set m
+                        if (hitm != 0ull) {
+                            if (m != 0) {
+                                const uint32_t o = m & 255u;
+                                vals[o] = vals[o] + dx[j];
+                                if (AND) mcnt[o] = (uint8_t)(mcnt[o] + 1);
+                            }
+                            dokm[j] &= ~hitm;   // scored through the table's owner
+                        }
                     }
                 }
             }
             // private postings: no other term has the doc: score == 0.0f + w*s == w*s exactly
+            if (!AND || T == 1) {   // conjunctive extension: one term alone never qualifies
 #pragma unroll
-            for (int j = 0; j < DE; j++) {
-                const bool scored = dok[j] && (!AND || T == 1);   // conjunctive extension: one term alone never qualifies
-                found_lane += scored ? 1u : 0u;
-                NS_OFFER(scored, dx[j], ps[j].x);
+                for (int j = 0; j < DE; j++) {
+                    found_s += (uint32_t)__popcll(dokm[j]);
+                    NS_OFFER_M(dokm[j], dx[j], ps[j].x);
+                }
             }
             d_cur += cnt;
             driver_progress = driver_progress || (cnt > 0);
@@ -399,19 +484,19 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
 #pragma unroll
             for (int j = 0; j < FE; j++) {
                 fin[j] = 0.0f;
-                scored[j] = fown[j];
-                if (fown[j]) {
-                    fin[j] = vals[fslot[j]];
-                    if (AND) scored[j] = (mcnt[fslot[j]] == (uint8_t)T);   // conjunctive extension: every term ref hit the doc
+                scored[j] = fmine[j];
+                if (fmine[j]) {
+                    fin[j] = vals[j * 64 + lane];
+                    if (AND) scored[j] = (mcnt[j * 64 + lane] == (uint8_t)T);   // conjunctive extension: every term ref hit the doc
                 }
             }
             wave_sync();
 #pragma unroll
             for (int j = 0; j < FE; j++) {
-                if (fown[j]) {   // the owner resets the slot for the next super-batch
-                    vals[fslot[j]] = __uint_as_float(kSentinelBits);
-                    keys[fslot[j]] = EMPTY;
-                    if (AND) mcnt[fslot[j]] = 0;
+                if (fmine[j]) {   // the owner resets its entry and accumulator for the next super-batch
+                    vals[j * 64 + lane] = __uint_as_float(kSentinelBits);
+                    ent[ftj[j] >> 14] = EMPTY;
+                    if (AND) mcnt[j * 64 + lane] = 0;
                 }
                 found_lane += scored[j] ? 1u : 0u;
                 NS_OFFER(scored[j], fin[j], fdoc[j]);
@@ -427,7 +512,10 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
     }
 #undef NS_FOREIGN_RMW
 #undef NS_OFFER
+#undef NS_OFFER_M
 #undef NS_PLAN_FOREIGN
+#undef NS_TAG
+#undef NS_IDENT
 
     // ---- this item's top-K ----
     wave_sync();
@@ -457,19 +545,20 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
     found += dpp_mov<0x143, 0xc>(0u, found);
     if (lane == 63) {
         out_nhits[it.out_slot] = n;
-        out_found[it.out_slot] = (uint64_t)found;
+        out_found[it.out_slot] = (uint64_t)found + (uint64_t)found_s;
     }
 }
 
+// HK = table entries per wave (4 per bucket)
 template <int HK, int FB, bool AND>
 __global__ void __launch_bounds__(256) k_dscore(const DevWItem* __restrict__ items, uint32_t n_items,
                                                 const DevTerm* __restrict__ terms, const DevSeg* __restrict__ segs,
                                                 Hit* __restrict__ out_hits, uint32_t* __restrict__ out_nhits,
                                                 uint64_t* __restrict__ out_found, uint32_t K) {
     constexpr int WPB = 4;                 // independent waves per workgroup
-    __shared__ __attribute__((aligned(16))) float s_vals[WPB][HK];
-    __shared__ __attribute__((aligned(16))) uint32_t s_keys[WPB][HK];
-    __shared__ __attribute__((aligned(16))) uint8_t s_mcnt[WPB][AND ? HK : 16];   // AND: term refs that hit the slot
+    __shared__ __attribute__((aligned(16))) uint32_t s_ent[WPB][HK];
+    __shared__ __attribute__((aligned(16))) float s_vals[WPB][FB];
+    __shared__ __attribute__((aligned(16))) uint8_t s_mcnt[WPB][AND ? FB : 16];   // AND: term refs that hit the doc
     __shared__ uint64_t s_cand[WPB][256];
     __shared__ __attribute__((aligned(16))) uint4 s_tab[WPB][64];   // per term: {idf, qweight, first posting - excl prefix, first posting}
     __shared__ uint32_t s_aux[WPB][64];
@@ -478,8 +567,8 @@ __global__ void __launch_bounds__(256) k_dscore(const DevWItem* __restrict__ ite
     const uint32_t item_idx = blockIdx.x * WPB + wave;
     if (item_idx >= n_items) return;   // whole wave leaves; there is no workgroup barrier in this kernel
     const DevWItem it = items[item_idx];
-    dscore_body<HK, FB, AND>(it, terms, segs, s_vals[wave], s_keys[wave], s_mcnt[wave], s_cand[wave], s_tab[wave], s_aux[wave],
-                             out_hits, out_nhits, out_found, K, lane);
+    dscore_body<HK / 4, FB, AND>(it, terms, segs, s_ent[wave], s_vals[wave], s_mcnt[wave], s_cand[wave], s_tab[wave], s_aux[wave],
+                                 out_hits, out_nhits, out_found, K, lane);
 }
 
 }  // namespace ns

@@ -53,7 +53,8 @@ struct DevWItem {
     uint32_t doc_lo;
     uint32_t doc_hi;
     uint32_t out_slot;
-    uint32_t whole;        // 1: range covers the whole segment (no start/end searches needed)
+    uint32_t whole;        // bit 0: range covers the whole segment (no start/end searches needed); bit 1: doc-tile body;
+                           // bit 2: thin foreign lists; bit 3: idf and norms in the short-division range (ns_div_short)
 };
 
 // Term group == the (query, segment) unit the boundary prepass works on.

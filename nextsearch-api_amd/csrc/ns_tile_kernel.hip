@@ -34,6 +34,7 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
 
     const DevSeg seg = segs[it.seg];
     const uint32_t T = it.term_count;
+    const bool fast_div = (__builtin_amdgcn_readfirstlane((int)it.whole) & 8) != 0;   // see ns_div_short
     const gp_u2 postings = (gp_u2)seg.postings;
     const gp_f32 pnorm = (gp_f32)seg.pnorm;
 
@@ -56,7 +57,7 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
         idf_bits = __float_as_uint(tm.idf);
         wq_bits = __float_as_uint(tm.weight);
         end = tm.count;
-        if (!it.whole) {
+        if (!(it.whole & 1u)) {
             const uint2* lst = seg.postings + tm.list_off;
             cur = list_lower_bound(lst, tm.count, it.doc_lo);
             end = list_lower_bound(lst, tm.count, it.doc_hi);
@@ -116,7 +117,7 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
                     // src/api_engine.cpp:477-480, operation for operation (k1 + 1.0f == 0x400CCCCD)
                     const float tf = (float)ps[j].y;
                     const float denom = tf + nr[j];
-                    const float sc = (idf * (tf * (1.2f + 1.0f))) / denom;
+                    const float sc = fast_div ? ns_div_short(idf * (tf * (1.2f + 1.0f)), denom) : (idf * (tf * (1.2f + 1.0f))) / denom;
                     x[j] = wq * sc;
                     if (ok[j]) old[j] = vals[ps[j].x - lo];   // all reads of the round first: docIds of one term are distinct
                 }
@@ -248,7 +249,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))
                                                 Hit* __restrict__ out_hits, uint32_t* __restrict__ out_nhits,
                                                 uint64_t* __restrict__ out_found, uint32_t K) {
     constexpr int WPB = 4;
-    __shared__ __attribute__((aligned(16))) uint32_t s_tbl[WPB][2 * HK];                 // values | keys, or one 2*HK-slot tile
+    __shared__ __attribute__((aligned(16))) uint32_t s_tbl[WPB][2 * HK];                 // HK/2 buckets of 4 entries, or one 2*HK-doc tile
+    __shared__ __attribute__((aligned(16))) float s_vals[WPB][FB];                       // driver body: one accumulator per foreign posting
     __shared__ __attribute__((aligned(16))) uint8_t s_mcnt[WPB][AND ? 2 * HK : 16];
     __shared__ uint64_t s_cand[WPB][CB];
     __shared__ __attribute__((aligned(16))) uint4 s_tab[WPB][TMAX];
@@ -260,15 +262,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))
     DevWItem it = items[item_idx];
     const bool tiles = (it.whole & 2u) != 0;
     const bool thin = (it.whole & 4u) != 0;   // the non-driver lists are thin: smallest foreign budget
-    it.whole &= 1u;
+    it.whole &= 9u;   // bit 0: whole segment, bit 3: short division
     if (thin)
-        dscore_body<HK, 64, AND, CB>(it, terms, segs, reinterpret_cast<float*>(s_tbl[wave]), s_tbl[wave] + HK, s_mcnt[wave], s_cand[wave],
+        dscore_body<HK / 2, 64, AND, CB>(it, terms, segs, s_tbl[wave], s_vals[wave], s_mcnt[wave], s_cand[wave],
                                  s_tab[wave], s_aux[wave], out_hits, out_nhits, out_found, K, lane);
     else if (tiles)
         tscore_body<2 * HK, AND, CB>(it, terms, segs, reinterpret_cast<float*>(s_tbl[wave]), s_mcnt[wave], s_cand[wave],
                                  out_hits, out_nhits, out_found, K, lane);
     else
-        dscore_body<HK, FB, AND, CB>(it, terms, segs, reinterpret_cast<float*>(s_tbl[wave]), s_tbl[wave] + HK, s_mcnt[wave], s_cand[wave],
+        dscore_body<HK / 2, FB, AND, CB>(it, terms, segs, s_tbl[wave], s_vals[wave], s_mcnt[wave], s_cand[wave],
                                  s_tab[wave], s_aux[wave], out_hits, out_nhits, out_found, K, lane);
 }
 

@@ -85,6 +85,35 @@ __device__ __forceinline__ uint32_t wave_shrink(uint64_t* cand, uint32_t n, floa
     return (uint32_t)r;
 }
 
+// ballot straight from the compare (HIP's __ballot goes through an int and costs two extra vector instructions)
+__device__ __forceinline__ uint64_t wballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+// a / b, correctly rounded.  `fast`: the caller guarantees a is +0 or in [2^-32, 2^64] and b in [2^-20, 2^34]
+// (checked on the host per item: idf in [2^-30, 2^30], norms in [2^-20, 2^30]); there v_div_scale_f32 scales
+// nothing and v_div_fixup_f32 fixes nothing, so the compiler's IEEE division sequence reduces to its core:
+// the SAME instructions on the SAME values, i.e. bit-identical results with three instructions less.
+__device__ __forceinline__ float ns_div_short(float a, float b) {
+    float r = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float q = a * r;
+    float t = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(t, r, q);
+    t = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(t, r, q);
+}
+// q[j] = a[j] / b[j] for N independent lanes-wide divisions; `fast` is wave-uniform (one scalar branch)
+template <int N>
+__device__ __forceinline__ void ns_div_n(float (&q)[N], const float (&a)[N], const float (&b)[N], bool fast) {
+    if (fast) {
+#pragma unroll
+        for (int j = 0; j < N; j++) q[j] = ns_div_short(a[j], b[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; j++) q[j] = a[j] / b[j];
+    }
+}
+
 __device__ __forceinline__ uint32_t list_lower_bound(const uint2* lst, uint32_t count, uint32_t doc) {
     uint32_t lo = 0, hi = count;
     while (lo < hi) {
@@ -199,7 +228,7 @@ __global__ void __launch_bounds__(256) k_wscore(const DevWItem* __restrict__ ite
         idf_bits = __float_as_uint(tm.idf);
         wq_bits = __float_as_uint(tm.weight);
         end = tm.count;
-        if (!it.whole) {
+        if (!(it.whole & 1u)) {
             const uint2* lst = seg.postings + tm.list_off;
             cur = list_lower_bound(lst, tm.count, it.doc_lo);
             end = list_lower_bound(lst, tm.count, it.doc_hi);
