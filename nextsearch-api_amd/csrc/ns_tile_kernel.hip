@@ -30,6 +30,7 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
     // CB: candidate buffer entries, a power of two >= K + 64
     constexpr int E = 4;                   // postings per lane per round
     constexpr int NG = TD / 256;           // float4 groups per lane in the tile read-back
+    constexpr bool kPrefetch = false;      // next-round prefetch: measured slower (more registers, the body is VALU-bound)
     static_assert(TD == 512 || TD == 1024 || TD == 2048, "TD must be 512, 1024 or 2048");
 
     const DevSeg seg = segs[it.seg];
@@ -49,11 +50,11 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
         for (int g = 0; g < NG; g++) m32[g * 64 + lane] = 0;
     }
 
-    // ---- lane t owns term t (posting indices are 32-bit: upload rejects segments of >= 2^32 postings) ----
-    uint32_t base = 0, cur = 0, end = 0, idf_bits = 0, wq_bits = 0;
+    // ---- lane t owns term t: absolute posting cursor, end, and the docId at the cursor (~0: exhausted).
+    //      Posting indices are 32-bit: upload rejects segments of >= 2^32 postings. ----
+    uint32_t cur = 0, end = 0, nd = 0xFFFFFFFFu, idf_bits = 0, wq_bits = 0;
     if ((uint32_t)lane < T) {
         const DevTerm tm = terms[it.term_begin + lane];
-        base = (uint32_t)tm.list_off;
         idf_bits = __float_as_uint(tm.idf);
         wq_bits = __float_as_uint(tm.weight);
         end = tm.count;
@@ -63,77 +64,160 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
             end = list_lower_bound(lst, tm.count, it.doc_hi);
             if (end < cur) end = cur;
         }
+        cur += (uint32_t)tm.list_off;
+        end += (uint32_t)tm.list_off;
+        if (cur < end) { const nat_u2 pv = postings[cur]; nd = pv.x; }
     }
 
     const uint32_t last_doc = it.doc_hi - 1;   // host guarantees doc_hi > doc_lo and doc_hi <= n_docs
     float theta = -__builtin_inff();
     uint32_t ncand = 0;
-    uint32_t found_lane = 0;
+    uint32_t found_s = 0;   // wave-uniform count (popcounts of ballots)
     wave_sync();
 
-    for (uint32_t lo = it.doc_lo;; lo += (uint32_t)TD) {
-        const uint32_t hi = min(lo + (uint32_t)(TD - 1), last_doc);
-        // fraction of the remaining doc range covered by this tile: sizes the rounds
-        const float frac = (float)(hi - lo + 1u) * __builtin_amdgcn_rcpf((float)(last_doc - lo + 1u));
+    // One round = up to E*64 postings of one term, loaded with a scalar base + a fixed lane offset (lanes
+    // past n read the next list or the buffer's padding and are masked).  The round that is expected to
+    // come next — the same term's next E*64 postings, the next term of the tile, or the first term of the
+    // next tile — is loaded into a second register set BEFORE the current round is processed, so its HBM
+    // latency overlaps the BM25 arithmetic, the LDS read-add-writes and the tile read-back.
+    nat_u2 ps[E], pn[E];
+    float nr[E], nn[E];
+    uint32_t pf_start = 0xFFFFFFFFu, pf_n = 0;   // the prefetched round: absolute posting index of its first posting, size
+#define NS_ISSUE(PS, NR, start, nn_)                                                               \
+    {                                                                                              \
+        const gp_u2 sp_ = postings + (start);                                                      \
+        const gp_f32 np_ = pnorm + (start);                                                        \
+        _Pragma("unroll") for (int j = 0; j < E; j++) {                                            \
+            if ((uint32_t)(j * 64) >= (nn_)) continue;   /* uniform: chunk beyond this round */    \
+            PS[j] = sp_[j * 64 + lane];                                                            \
+            NR[j] = np_[j * 64 + lane];                                                            \
+        }                                                                                          \
+    }
+#define NS_ROUND_SIZE(rem_, want_) min(min((rem_), (uint32_t)(E * 64)), max((want_), 64u))
+#pragma unroll
+    for (int j = 0; j < E; j++) { ps[j] = nat_u2{0xFFFFFFFFu, 0u}; pn[j] = nat_u2{0xFFFFFFFFu, 0u}; nr[j] = 1.0f; nn[j] = 1.0f; }
 
-        // ---- terms in query order ----
-        for (uint32_t t = 0; t < T; t++) {
-            const uint32_t s_base = rdlane(base, t);
+    // ---- tile header: the next tile starts at the first doc that still has a posting (empty doc space costs nothing) ----
+    uint32_t lo = it.doc_lo, hi = 0;
+    float frac = 0.0f;
+    uint64_t act = 0ull;
+    bool done = false;
+#define NS_TILE_HEADER()                                                                           \
+    {                                                                                              \
+        const uint32_t mind_ = wave_min_dpp(nd);                                                   \
+        done = mind_ > last_doc;                                                                   \
+        if (!done) {                                                                               \
+            if (mind_ > lo) lo = mind_;                                                            \
+            hi = (last_doc - lo >= (uint32_t)TD) ? (lo + (uint32_t)(TD - 1)) : last_doc;           \
+            /* fraction of the remaining doc range covered by this tile: sizes the rounds */       \
+            frac = (float)(hi - lo + 1u) * __builtin_amdgcn_rcpf((float)(last_doc - lo + 1u));     \
+            act = wballot(nd <= hi);                                                               \
+        }                                                                                          \
+    }
+    NS_TILE_HEADER();
+    while (!done) {
+        const uint32_t tile_lo = lo, tile_hi = hi;
+        // ---- the terms that have postings in this tile, in query order (the fp32 accumulation order) ----
+        while (act != 0ull) {
+            const uint32_t t = (uint32_t)__builtin_ctzll(act);
+            act &= act - 1ull;
             uint32_t s_cur = rdlane(cur, t);
             const uint32_t s_end = rdlane(end, t);
-            if (s_cur >= s_end) continue;
             const float idf = __uint_as_float(rdlane(idf_bits, t));
             const float wq = __uint_as_float(rdlane(wq_bits, t));
             uint32_t want = 16u + (uint32_t)((float)(s_end - s_cur) * frac * 1.125f);
+            uint32_t s_nd = 0xFFFFFFFFu;
             for (;;) {
                 const uint32_t remd = s_end - s_cur;
                 if (remd == 0) break;
-                const uint32_t n = min(min(remd, (uint32_t)(E * 64)), max(want, 64u));
-                want = (want > n) ? (want - n) : 64u;
-                nat_u2 ps[E];
-                float nr[E];
+                uint32_t n;
+                if (kPrefetch && pf_start == s_cur) {   // the prefetched round is this one
+                    n = pf_n;
 #pragma unroll
-                for (int j = 0; j < E; j++) {
-                    ps[j] = nat_u2{0xFFFFFFFFu, 0u};
-                    nr[j] = 1.0f;
-                    if ((uint32_t)(j * 64) >= n) continue;   // uniform: chunk beyond this round
-                    const uint32_t p = (uint32_t)(j * 64 + lane);
-                    const uint32_t idx = s_base + s_cur + ((p < n) ? p : 0u);
-                    ps[j] = postings[idx];
-                    nr[j] = pnorm[idx];
-                    ps[j].x = (p < n) ? ps[j].x : 0xFFFFFFFFu;   // docId ~0 is never <= hi
+                    for (int j = 0; j < E; j++) { ps[j] = pn[j]; nr[j] = nn[j]; }
+                } else {
+                    n = NS_ROUND_SIZE(remd, want);
+                    NS_ISSUE(ps, nr, s_cur, n);
                 }
+                const bool expect_more = want > n;
+                want = expect_more ? (want - n) : 64u;
+                // ---- prefetch the round expected next ----
+                pf_start = 0xFFFFFFFFu;
+                if (!kPrefetch) {
+                } else if (expect_more && s_cur + n < s_end) {
+                    pf_start = s_cur + n;
+                    pf_n = NS_ROUND_SIZE(s_end - pf_start, want);
+                } else if (act != 0ull) {
+                    const uint32_t t2 = (uint32_t)__builtin_ctzll(act);
+                    pf_start = rdlane(cur, t2);
+                    const uint32_t rem2 = rdlane(end, t2) - pf_start;   // > 0: an active term has a posting at its cursor
+                    pf_n = NS_ROUND_SIZE(rem2, 16u + (uint32_t)((float)rem2 * frac * 1.125f));
+                }
+                if (pf_start != 0xFFFFFFFFu) NS_ISSUE(pn, nn, pf_start, pf_n);
+
                 uint32_t cnt = 0;
-                float x[E], old[E];
-                bool ok[E];
+                uint64_t takem[E];
+                float x[E];
+                {   // src/api_engine.cpp:477-480, operation for operation (k1 + 1.0f == 0x400CCCCD)
+                    float num[E], den[E];
+#pragma unroll
+                    for (int j = 0; j < E; j++) {
+                        const uint32_t left = (n > (uint32_t)(j * 64)) ? (n - (uint32_t)(j * 64)) : 0u;   // scalar
+                        const uint64_t nmask = (left >= 64u) ? ~0ull : ((1ull << left) - 1ull);
+                        takem[j] = wballot(ps[j].x <= tile_hi) & nmask;
+                        cnt += (uint32_t)__popcll(takem[j]);
+                        const float tf = (float)ps[j].y;
+                        den[j] = tf + nr[j];
+                        num[j] = idf * (tf * (1.2f + 1.0f));
+                    }
+                    ns_div_n<E>(x, num, den, fast_div);
+                }
+                // read-add-write on the doc's slot; all reads of the round first (docIds of one term are distinct).
+                // The slot index is masked: a corrupt (unsorted) list cannot leave the tile.
+                float old[E];
+                uint32_t slot[E];
 #pragma unroll
                 for (int j = 0; j < E; j++) {
-                    ok[j] = false; x[j] = 0.0f; old[j] = 0.0f;
-                    if ((uint32_t)(j * 64) >= n) continue;   // uniform
-                    const bool take = ps[j].x <= hi;
-                    cnt += (uint32_t)__popcll(__ballot(take));
-                    // docId < lo only for corrupt (unsorted) lists: consumed, not scored
-                    ok[j] = take && (ps[j].x >= lo);
-                    // src/api_engine.cpp:477-480, operation for operation (k1 + 1.0f == 0x400CCCCD)
-                    const float tf = (float)ps[j].y;
-                    const float denom = tf + nr[j];
-                    const float sc = fast_div ? ns_div_short(idf * (tf * (1.2f + 1.0f)), denom) : (idf * (tf * (1.2f + 1.0f))) / denom;
-                    x[j] = wq * sc;
-                    if (ok[j]) old[j] = vals[ps[j].x - lo];   // all reads of the round first: docIds of one term are distinct
+                    slot[j] = (ps[j].x - tile_lo) & (uint32_t)(TD - 1);
+                    old[j] = 0.0f;
+                    if (takem[j] == 0ull) continue;   // uniform
+                    if (__builtin_amdgcn_inverse_ballot_w64(takem[j])) old[j] = vals[slot[j]];
                 }
 #pragma unroll
                 for (int j = 0; j < E; j++) {
-                    if (ok[j]) {
-                        const uint32_t slot = ps[j].x - lo;
-                        vals[slot] = old[j] + x[j];   // -0.0f (untouched) + x == x exactly
-                        if (AND) mcnt[slot] = (uint8_t)(mcnt[slot] + 1);
+                    if (takem[j] == 0ull) continue;   // uniform
+                    if (__builtin_amdgcn_inverse_ballot_w64(takem[j])) {
+                        vals[slot[j]] = old[j] + wq * x[j];   // -0.0f (untouched) + x == x exactly
+                        if (AND) mcnt[slot[j]] = (uint8_t)(mcnt[slot[j]] + 1);
                     }
                 }
                 s_cur += cnt;
-                if (cnt < n) break;   // reached the end of the tile
+                if (cnt < n) {   // reached the end of the tile: the first posting not taken is the term's next doc
+#pragma unroll
+                    for (int j = 0; j < E; j++)
+                        if ((cnt >> 6) == (uint32_t)j) s_nd = rdlane(ps[j].x, cnt & 63u);   // uniform
+                    break;
+                }
             }
-            if ((uint32_t)lane == t) cur = s_cur;
+            if ((uint32_t)lane == t) { cur = s_cur; nd = s_nd; }
             wave_sync();   // the next term's read-add-writes follow this term's
+        }
+
+        // ---- header of the NEXT tile, and the first round of its first term goes out before the read-back ----
+        if (tile_hi >= last_doc) { done = true; }
+        else {
+            lo = tile_hi + 1u;
+            NS_TILE_HEADER();
+            if (kPrefetch && !done && act != 0ull) {
+                const uint32_t t0 = (uint32_t)__builtin_ctzll(act);
+                const uint32_t st0 = rdlane(cur, t0);
+                if (pf_start != st0) {
+                    const uint32_t rem0 = rdlane(end, t0) - st0;
+                    pf_start = st0;
+                    pf_n = NS_ROUND_SIZE(rem0, 16u + (uint32_t)((float)rem0 * frac * 1.125f));
+                    NS_ISSUE(pn, nn, pf_start, pf_n);
+                }
+            }
         }
 
         // ---- read the tile back: found, candidates, reset ----
@@ -144,37 +228,31 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
             const float vv[4] = {q.x, q.y, q.z, q.w};
             uint32_t cw = 0;
             if (AND) cw = reinterpret_cast<const uint32_t*>(mcnt)[g * 64 + lane];
-            bool any = false;
-            bool sc_[4];
-            bool anyq = false;
+            uint64_t scm[4];
+            uint64_t anyq = 0ull;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                bool touched = __float_as_uint(vv[c]) != kSentinelBits;
-                any = any || touched;
-                if (AND) touched = touched && (((cw >> (8 * c)) & 0xFFu) == T);   // conjunctive extension
-                sc_[c] = touched;
-                found_lane += touched ? 1u : 0u;
-                anyq = anyq || (touched && vv[c] > theta);
+                scm[c] = wballot(__float_as_uint(vv[c]) != kSentinelBits);
+                if (AND) scm[c] &= wballot(((cw >> (8 * c)) & 0xFFu) == T);   // conjunctive extension
+                found_s += (uint32_t)__popcll(scm[c]);
+                anyq |= scm[c] & wballot(vv[c] > theta);
             }
-            if (any) {
-                v4[g * 64 + lane] = sent4;
-                if (AND) reinterpret_cast<uint32_t*>(mcnt)[g * 64 + lane] = 0;
-            }
-            if (__ballot(anyq) != 0ull) {
+            v4[g * 64 + lane] = sent4;
+            if (AND) reinterpret_cast<uint32_t*>(mcnt)[g * 64 + lane] = 0;
+            if (anyq != 0ull) {
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    bool qf = sc_[c] && (ge_mode ? (vv[c] >= theta) : (vv[c] > theta));
-                    unsigned long long mask = __ballot(qf);
+                    uint64_t mask = scm[c] & (ge_mode ? wballot(vv[c] >= theta) : wballot(vv[c] > theta));
                     if (mask != 0ull) {
                         uint32_t n = (uint32_t)__popcll(mask);
                         if (ncand + n > (uint32_t)CB) {
                             ncand = wave_shrink(cand, ncand, theta, K, lane);
                             ge_mode = true;
-                            qf = sc_[c] && (vv[c] >= theta);
-                            mask = __ballot(qf);
+                            mask = scm[c] & wballot(vv[c] >= theta);
                             n = (uint32_t)__popcll(mask);
                         }
-                        if (qf) cand[ncand + lanes_below(mask)] = make_key(vv[c], lo + (uint32_t)((g * 64 + lane) * 4 + c));
+                        if (__builtin_amdgcn_inverse_ballot_w64(mask))
+                            cand[ncand + lanes_below(mask)] = make_key(vv[c], tile_lo + (uint32_t)((g * 64 + lane) * 4 + c));
                         ncand += n;
                     }
                 }
@@ -182,10 +260,10 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
         }
         wave_sync();
         if (ncand > (uint32_t)(CB / 2)) ncand = wave_shrink(cand, ncand, theta, K, lane);
-        if (hi >= last_doc) break;
-        // nothing left in any list: done
-        if (__ballot(((uint32_t)lane < T) && (cur < end)) == 0ull) break;
     }
+#undef NS_ISSUE
+#undef NS_ROUND_SIZE
+#undef NS_TILE_HEADER
 
     // ---- this item's top-K ----
     wave_sync();
@@ -206,16 +284,9 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
         }
         oh[i] = h;
     }
-    uint32_t found = found_lane;
-    found += dpp_mov<0x111, 0xf>(0u, found);
-    found += dpp_mov<0x112, 0xf>(0u, found);
-    found += dpp_mov<0x114, 0xf>(0u, found);
-    found += dpp_mov<0x118, 0xf>(0u, found);
-    found += dpp_mov<0x142, 0xa>(0u, found);
-    found += dpp_mov<0x143, 0xc>(0u, found);
     if (lane == 63) {
         out_nhits[it.out_slot] = n;
-        out_found[it.out_slot] = (uint64_t)found;
+        out_found[it.out_slot] = (uint64_t)found_s;
     }
 }
 
@@ -228,7 +299,7 @@ __global__ void __launch_bounds__(256) k_tscore(const DevWItem* __restrict__ ite
     __shared__ __attribute__((aligned(16))) float s_vals[WPB][TD];
     __shared__ __attribute__((aligned(16))) uint8_t s_mcnt[WPB][AND ? TD : 16];   // AND: term refs that hit the slot
     __shared__ uint64_t s_cand[WPB][256];
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: the item is fetched with scalar loads
     const int lane = threadIdx.x & 63;
     const uint32_t item_idx = blockIdx.x * WPB + wave;
     if (item_idx >= n_items) return;   // whole wave leaves; there is no workgroup barrier in this kernel
@@ -241,8 +312,8 @@ __global__ void __launch_bounds__(256) k_tscore(const DevWItem* __restrict__ ite
 // dense groups (tscore_body; DevWItem::whole bit 1).  One launch, one LDS budget: the tile body's
 // 2*HK-slot table aliases the driver body's HK values + HK keys.
 // TMAX: most terms a group may have in this instantiation (16: smaller term tables, 3 KB less LDS per
-// workgroup — with K > 64 that is the 6th workgroup per CU; 64: the general case, launched only when needed).
-// Forcing 72 VGPRs for a 7th workgroup (amdgpu_waves_per_eu) spills and measured no faster.
+// workgroup; 64: the general case, launched only when needed).  An 8-entry instantiation reaches 7
+// workgroups per CU (23.2 KB LDS, 69 VGPRs) and measured 1.5% slower: the kernel is VALU-bound.
 template <int HK, int FB, bool AND, int CB, int TMAX>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) k_uscore(const DevWItem* __restrict__ items, uint32_t n_items,
                                                 const DevTerm* __restrict__ terms, const DevSeg* __restrict__ segs,
@@ -255,7 +326,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))
     __shared__ uint64_t s_cand[WPB][CB];
     __shared__ __attribute__((aligned(16))) uint4 s_tab[WPB][TMAX];
     __shared__ uint32_t s_aux[WPB][TMAX];
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: the item is fetched with scalar loads
     const int lane = threadIdx.x & 63;
     const uint32_t item_idx = blockIdx.x * WPB + wave;
     if (item_idx >= n_items) return;   // whole wave leaves; there is no workgroup barrier in this kernel

@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(256) k_wscore(const DevWItem* __restrict__ ite
     __shared__ __attribute__((aligned(16))) uint4 s_tab[WPB][64];   // per term: {idf, qweight, first posting - excl prefix, first posting}
     __shared__ uint32_t s_aux[WPB][64];                              // T > 8: inclusive window prefix; then: new cursors
 
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: the item is fetched with scalar loads
     const int lane = threadIdx.x & 63;
     const uint32_t item_idx = blockIdx.x * WPB + wave;
     if (item_idx >= n_items) return;   // whole wave leaves; there is no workgroup barrier in this kernel
