@@ -104,7 +104,7 @@ static constexpr uint32_t kDefaultSplitPostings = 32768;   // forced variants: p
 // auto mode: work units per item (one unit = one streamed driver posting).  Every item pays for its own
 // top-K warm-up and its K-row partial result, so large K wants fewer, longer items (sweeps: profiles/r01).
 static constexpr uint32_t kSplitWorkSmallK = 98304, kSplitWorkLargeK = 262144;
-static constexpr uint64_t kWorkForeign = 8, kWorkTile = 3;
+static constexpr uint64_t kWorkForeign = 8, kWorkTile = 2;
 
 template <int D, int HK>
 static void launch_wscore(bool and_mode, uint32_t n_items, hipStream_t st, const DevWItem* items, const DevTerm* terms,
@@ -466,15 +466,15 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
             hg.g.term_count = (uint32_t)dterms.size() - hg.g.term_begin;
             if ((flags & NS_FLAG_AND) && hg.g.term_count > 255) return fail(ctx, NS_E_INVAL, "AND mode supports at most 255 term refs per (query, segment)");
             hg.wave = wave_path && hg.g.term_count <= kWaveMaxTerms;
-            // class of the group (auto mode only): which scoring body suits its mix of lists (measured on
-            // MI355X, profiles/r01): 2 = very dense (>= 0.7 postings per doc over >= 2 lists): doc tiles;
-            // 1 = one list dominates (the others hold <= 1/16 of its postings): driver stream with the
-            // 64-posting foreign budget; 0 = driver stream with the 128-posting budget.
+            // class of the group (auto mode only): which scoring body suits its mix of lists (sweeps on
+            // MI355X, profiles/r01): 1 = one list dominates (the others hold <= 1/32 of its postings): driver
+            // stream with the 64-posting foreign budget; 2 = dense (>= 0.25 postings per doc over >= 2
+            // lists): doc tiles; 0 = driver stream with the 128-posting budget.
             {
                 const uint64_t rest = hg.cost - hg.cmax;
                 const uint32_t nd = std::max<uint32_t>(segs[sid].n_docs, 1);
-                if (hg.g.term_count >= 2 && hg.cost * 10 >= (uint64_t)nd * 7) hg.cls = 2;
-                else if (rest * 16 <= hg.cmax) hg.cls = 1;
+                if (rest * 32 <= hg.cmax) hg.cls = 1;
+                else if (hg.g.term_count >= 2 && hg.cost * 4 >= (uint64_t)nd) hg.cls = 2;
                 else hg.cls = 0;
                 // work estimate in units of one streamed driver posting (measured, profiles/r01): a foreign
                 // posting (claim, accumulate, read back) costs ~10x, a doc-tile posting ~3x

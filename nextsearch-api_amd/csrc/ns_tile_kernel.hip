@@ -158,31 +158,42 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
                 uint32_t cnt = 0;
                 uint64_t takem[E];
                 float x[E];
-                {   // src/api_engine.cpp:477-480, operation for operation (k1 + 1.0f == 0x400CCCCD)
-                    float num[E], den[E];
-#pragma unroll
-                    for (int j = 0; j < E; j++) {
-                        const uint32_t left = (n > (uint32_t)(j * 64)) ? (n - (uint32_t)(j * 64)) : 0u;   // scalar
-                        const uint64_t nmask = (left >= 64u) ? ~0ull : ((1ull << left) - 1ull);
-                        takem[j] = wballot(ps[j].x <= tile_hi) & nmask;
-                        cnt += (uint32_t)__popcll(takem[j]);
-                        const float tf = (float)ps[j].y;
-                        den[j] = tf + nr[j];
-                        num[j] = idf * (tf * (1.2f + 1.0f));
-                    }
-                    ns_div_n<E>(x, num, den, fast_div);
-                }
-                // read-add-write on the doc's slot; all reads of the round first (docIds of one term are distinct).
-                // The slot index is masked: a corrupt (unsorted) list cannot leave the tile.
                 float old[E];
                 uint32_t slot[E];
 #pragma unroll
-                for (int j = 0; j < E; j++) {
-                    slot[j] = (ps[j].x - tile_lo) & (uint32_t)(TD - 1);
-                    old[j] = 0.0f;
-                    if (takem[j] == 0ull) continue;   // uniform
-                    if (__builtin_amdgcn_inverse_ballot_w64(takem[j])) old[j] = vals[slot[j]];
+                for (int j = 0; j < E; j++) { takem[j] = 0ull; x[j] = 0.0f; old[j] = 0.0f; slot[j] = 0; }
+                // A round holds 1..E chunks of 64 postings; the work is done per PAIR of chunks (the compiler
+                // packs the two BM25 evaluations into v_pk_* instructions), and the second pair only if it has postings.
+#define NS_TILE_PAIR(J0, NJ)                                                                         \
+                {   /* src/api_engine.cpp:477-480, operation for operation (k1 + 1.0f == 0x400CCCCD) */ \
+                    float num_[NJ], den_[NJ], q_[NJ];                                              \
+                    _Pragma("unroll") for (int jj = 0; jj < (NJ); jj++) {                          \
+                        const int j = (J0) + jj;                                                   \
+                        const uint32_t left = (n > (uint32_t)(j * 64)) ? (n - (uint32_t)(j * 64)) : 0u;   /* scalar */ \
+                        const uint64_t nmask = (left >= 64u) ? ~0ull : ((1ull << left) - 1ull);    \
+                        takem[j] = wballot(ps[j].x <= tile_hi) & nmask;                            \
+                        cnt += (uint32_t)__popcll(takem[j]);                                       \
+                        const float tf = (float)ps[j].y;                                           \
+                        den_[jj] = tf + nr[j];                                                     \
+                        num_[jj] = idf * (tf * (1.2f + 1.0f));                                     \
+                    }                                                                              \
+                    ns_div_n<NJ>(q_, num_, den_, fast_div);                                        \
+                    _Pragma("unroll") for (int jj = 0; jj < (NJ); jj++) x[(J0) + jj] = q_[jj];       \
+                    /* read-add-write on the doc's slot; all reads of the round first (docIds of one term are */ \
+                    /* distinct).  The slot index is masked: a corrupt (unsorted) list cannot leave the tile. */ \
+                    _Pragma("unroll") for (int jj = 0; jj < (NJ); jj++) {                          \
+                        const int j = (J0) + jj;                                                   \
+                        slot[j] = (ps[j].x - tile_lo) & (uint32_t)(TD - 1);                        \
+                        if (takem[j] == 0ull) continue;   /* uniform */                            \
+                        if (__builtin_amdgcn_inverse_ballot_w64(takem[j])) old[j] = vals[slot[j]]; \
+                        /* `found` (:495) counts a doc when its slot is touched for the first time (OR mode; the */ \
+                        /* conjunctive extension counts in the read-back, where the per-doc term counts are known) */ \
+                        if (!AND) found_s += (uint32_t)__popcll(takem[j] & wballot(__float_as_uint(old[j]) == kSentinelBits)); \
+                    }                                                                              \
                 }
+                if (n <= 64u) NS_TILE_PAIR(0, 1) else NS_TILE_PAIR(0, 2);
+                if (n > 192u) NS_TILE_PAIR(2, 2) else if (n > 128u) NS_TILE_PAIR(2, 1);
+#undef NS_TILE_PAIR
 #pragma unroll
                 for (int j = 0; j < E; j++) {
                     if (takem[j] == 0ull) continue;   // uniform
@@ -220,25 +231,32 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
             }
         }
 
-        // ---- read the tile back: found, candidates, reset ----
+        // ---- read the tile back: candidates, reset (and, for the conjunctive extension, found) ----
         bool ge_mode = false;   // after a shrink INSIDE this tile, ties with theta may still win on docId
 #pragma unroll
         for (int g = 0; g < NG; g++) {
             const float4 q = v4[g * 64 + lane];
             const float vv[4] = {q.x, q.y, q.z, q.w};
+            v4[g * 64 + lane] = sent4;
             uint32_t cw = 0;
-            if (AND) cw = reinterpret_cast<const uint32_t*>(mcnt)[g * 64 + lane];
+            if (AND) { cw = reinterpret_cast<const uint32_t*>(mcnt)[g * 64 + lane]; reinterpret_cast<uint32_t*>(mcnt)[g * 64 + lane] = 0; }
+            // Once K candidates with non-negative scores exist (theta >= 0) an untouched slot (-0.0f) can
+            // never beat theta: one max + one compare per four slots decides whether anything is offered.
+            if (!AND && theta >= 0.0f && !ge_mode) {
+                const float mx = __builtin_fmaxf(__builtin_fmaxf(vv[0], vv[1]), __builtin_fmaxf(vv[2], vv[3]));
+                if (wballot(mx > theta) == 0ull) continue;
+            }
             uint64_t scm[4];
             uint64_t anyq = 0ull;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 scm[c] = wballot(__float_as_uint(vv[c]) != kSentinelBits);
-                if (AND) scm[c] &= wballot(((cw >> (8 * c)) & 0xFFu) == T);   // conjunctive extension
-                found_s += (uint32_t)__popcll(scm[c]);
+                if (AND) {
+                    scm[c] &= wballot(((cw >> (8 * c)) & 0xFFu) == T);   // conjunctive extension
+                    found_s += (uint32_t)__popcll(scm[c]);
+                }
                 anyq |= scm[c] & wballot(vv[c] > theta);
             }
-            v4[g * 64 + lane] = sent4;
-            if (AND) reinterpret_cast<uint32_t*>(mcnt)[g * 64 + lane] = 0;
             if (anyq != 0ull) {
 #pragma unroll
                 for (int c = 0; c < 4; c++) {

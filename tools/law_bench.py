@@ -47,6 +47,19 @@ def laws():
     L["cfg5_1hot"] = ([q for q in q5 if sum(1 for t in q.split() if rank_of(t) <= 32) == 1], 10)
     L["cfg5_1hot_multi"] = ([q for q in q5 if sum(1 for t in q.split() if rank_of(t) <= 32) == 1 and len(q.split()) > 1], 10)
     L["cfg5_2hot"] = ([q for q in q5 if sum(1 for t in q.split() if rank_of(t) <= 32) >= 2], 10)
+    # cfg5's two-hot class split the way ns_batch_prepare classifies (df = 0.6 N / rank on the synthetic index)
+    def cls_of(q):
+        dfs = [600000.0 / rank_of(t) for t in q.split()]
+        cost, cmax = sum(dfs), max(dfs)
+        rest = cost - cmax
+        if rest * 32 <= cmax:
+            return "thin"
+        if len(dfs) >= 2 and cost * 100 >= 1_000_000 * 25:
+            return "tile"
+        return "gen"
+    for c in ("thin", "tile", "gen"):
+        L["cfg5_2hot_" + c] = ([q for q in L["cfg5_2hot"][0] if cls_of(q) == c], 10)
+        L["cfg5_" + c] = ([q for q in q5 if cls_of(q) == c], 10)
     L["cfg3"] = (workloads.cfg3_queries(), 100)
     return L
 
@@ -69,6 +82,9 @@ def main():
     print(f"{'law':>14} {'Q':>6} {'post/q':>9} {'items':>7} {'kern_ms':>9} {'ns/post':>8} {'GB/s':>8} {'frac':>6}")
     for n in names:
         qs, k = L[n]
+        if not qs:
+            print(f"{n:>14}      0")
+            continue
         b = eng.prepare(qs, k)
         b.run(False)
         b.sync()
