@@ -94,7 +94,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
     {
         const uint32_t remv = end - cur;
         const uint32_t mx = wave_max_dpp(remv);
-        dl = (uint32_t)__builtin_ctzll(__ballot(remv == mx && (uint32_t)lane < T) | (1ull << 63));
+        dl = (uint32_t)__builtin_ctzll(wballot(remv == mx && (uint32_t)lane < T) | (1ull << 63));
         if (dl >= T) dl = 0;
     }
     uint32_t d_cur = rdlane(cur, dl);
@@ -123,15 +123,16 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
     // offer (score, doc) of the lanes where `cond` holds to the candidate buffer
 #define NS_OFFER(cond, scorev, docv)                                                               \
     {                                                                                              \
-        bool qf_ = (cond) && (ge_mode ? ((scorev) >= theta) : ((scorev) > theta));                 \
-        unsigned long long mask_ = __ballot(qf_);                                                  \
+        bool qf_ = (cond) && ((scorev) > theta);                                                   \
+        if (ge_mode) qf_ = (cond) && ((scorev) >= theta);   /* rare: after a shrink inside this super-batch */ \
+        unsigned long long mask_ = wballot(qf_);                                                   \
         if (mask_ != 0ull) {                                                                       \
             uint32_t n_ = (uint32_t)__popcll(mask_);                                               \
             if (ncand + n_ > (uint32_t)CB) {                                                       \
                 ncand = wave_shrink(cand, ncand, theta, K, lane);                                  \
                 ge_mode = true;                                                                    \
                 qf_ = (cond) && ((scorev) >= theta);                                               \
-                mask_ = __ballot(qf_);                                                             \
+                mask_ = wballot(qf_);                                                              \
                 n_ = (uint32_t)__popcll(mask_);                                                    \
             }                                                                                      \
             if (qf_) cand[ncand + lanes_below(mask_)] = make_key((scorev), (docv));                \
@@ -142,7 +143,9 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
     // the same with the condition given as a lane mask in SGPRs
 #define NS_OFFER_M(condm, scorev, docv)                                                            \
     {                                                                                              \
-        uint64_t mask_ = (condm) & (ge_mode ? wballot((scorev) >= theta) : wballot((scorev) > theta)); \
+        uint64_t mask_ = wballot((scorev) > theta);                                                \
+        if (ge_mode) mask_ = wballot((scorev) >= theta);   /* rare: only after a shrink inside this super-batch */ \
+        mask_ &= (condm);                                                                          \
         if (mask_ != 0ull) {                                                                       \
             uint32_t n_ = (uint32_t)__popcll(mask_);                                               \
             if (ncand + n_ > (uint32_t)CB) {                                                       \
@@ -163,7 +166,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
 #define NS_PLAN_FOREIGN()                                                                          \
     {                                                                                              \
         const uint32_t rem_ = end - cur;   /* 0 for the driver's lane and lanes >= T */            \
-        const uint32_t nact_ = (uint32_t)__popcll(__ballot(rem_ > 0));                             \
+        const uint32_t nact_ = (uint32_t)__popcll(wballot(rem_ > 0));                             \
         const float scale_ = (float)(FB - (int)nact_) * __builtin_amdgcn_rcpf((float)max(Rf, 1u)); \
         uint32_t w_ = 1u + (uint32_t)((float)rem_ * scale_);                                       \
         w_ = (w_ < rem_) ? w_ : rem_;                                                              \
@@ -243,7 +246,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
                     const bool take = pst[j].x <= hi;
                     fok[j] = take && (pst[j].x >= lo);   // docId < lo only for corrupt (unsorted) lists: consumed, not scored
                     fdoc[j] = pst[j].x;
-                    const unsigned long long m = __ballot(take);
+                    const unsigned long long m = wballot(take);
                     const bool prev_take = (((m << 1) | prev_last) >> lane) & 1ull;
                     prev_last = m >> 63;
                     const bool first_untaken = ((uint32_t)(j * 64 + lane) < total) && !take &&
@@ -312,8 +315,8 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
                 bool scan = pending;   // lanes that have to read their (new) bucket
                 uint32_t pos = 0;
                 for (int round = 0; round < 8 * NB; round++) {
-                    if (__ballot(pending) == 0ull) break;
-                    if (__ballot(scan) != 0ull) {
+                    if (wballot(pending) == 0ull) break;
+                    if (wballot(scan) != 0ull) {
                         if (scan) {
                             const uint4 q = ent4[b];
                             uint32_t m = 0;   // the entry of the same docId, if any
@@ -387,15 +390,23 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
                 ps[j] = sp[j * 64 + lane];
                 nr[j] = np[j * 64 + lane];
             }
-            uint32_t cnt = 0;
+            uint32_t cnt = 0, r_hits = 0;
             float dx[DE];
             uint64_t dokm[DE];   // postings of this round that belong to the super-batch and are still private
+            if (n == (uint32_t)(DE * 64)) {   // a full round (all but a list's last): no lane mask to build
 #pragma unroll
-            for (int j = 0; j < DE; j++) {
-                const uint32_t left = (n > (uint32_t)(j * 64)) ? (n - (uint32_t)(j * 64)) : 0u;   // scalar
-                const uint64_t nmask = (left >= 64u) ? ~0ull : ((1ull << left) - 1ull);
-                dokm[j] = wballot(ps[j].x <= hi) & nmask;
-                cnt += (uint32_t)__popcll(dokm[j]);
+                for (int j = 0; j < DE; j++) {
+                    dokm[j] = wballot(ps[j].x <= hi);
+                    cnt += (uint32_t)__popcll(dokm[j]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < DE; j++) {
+                    const uint32_t left = (n > (uint32_t)(j * 64)) ? (n - (uint32_t)(j * 64)) : 0u;   // scalar
+                    const uint64_t nmask = (left >= 64u) ? ~0ull : ((1ull << left) - 1ull);
+                    dokm[j] = wballot(ps[j].x <= hi) & nmask;
+                    cnt += (uint32_t)__popcll(dokm[j]);
+                }
             }
             {   // src/api_engine.cpp:477-480, operation for operation
                 float num[DE], den[DE];
@@ -459,15 +470,16 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
                                 if (AND) mcnt[o] = (uint8_t)(mcnt[o] + 1);
                             }
                             dokm[j] &= ~hitm;   // scored through the table's owner
+                            r_hits += (uint32_t)__popcll(hitm);
                         }
                     }
                 }
             }
             // private postings: no other term has the doc: score == 0.0f + w*s == w*s exactly
             if (!AND || T == 1) {   // conjunctive extension: one term alone never qualifies
+                found_s += cnt - r_hits;   // every taken posting that did not join a table entry is a doc of its own
 #pragma unroll
                 for (int j = 0; j < DE; j++) {
-                    found_s += (uint32_t)__popcll(dokm[j]);
                     NS_OFFER_M(dokm[j], dx[j], ps[j].x);
                 }
             }

@@ -60,6 +60,8 @@ def laws():
     for c in ("thin", "tile", "gen"):
         L["cfg5_2hot_" + c] = ([q for q in L["cfg5_2hot"][0] if cls_of(q) == c], 10)
         L["cfg5_" + c] = ([q for q in q5 if cls_of(q) == c], 10)
+    L["cfg5_1hot_gen"] = ([q for q in L["cfg5_1hot"][0] if cls_of(q) == "gen"], 10)
+    L["cfg5_nohot_gen"] = ([q for q in L["cfg5_nohot"][0] if cls_of(q) == "gen"], 10)
     L["cfg3"] = (workloads.cfg3_queries(), 100)
     return L
 
