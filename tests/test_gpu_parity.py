@@ -172,6 +172,35 @@ def test_raw_abi_weights_and_errors(engines):
     assert rc == 0 and nhits[0] == 0 and found[0] == 0 and nhits[1] == 10
 
 
+def test_idf_outside_short_division_range_scales_exactly(engines):
+    """The BM25 division takes its short form only when every idf of a group is in [2^-30, 2^30]
+    (ns_div_short); outside it the full IEEE sequence runs.  Scaling every idf by 2^40 is exact in
+    fp32 (no overflow here), so docs, order and `found` must be identical and every score exactly
+    2^40 times the in-range one: the two division paths agree bit for bit."""
+    g, eng, ora = engines("mid1")
+    terms = ["covid", "t000050", "t000012", "t000300"]
+    ent = [eng.lookup(0, t) for t in terms]
+    qd = np.array([(0, 4), (4, 2), (6, 1)], dtype=nsbind.QDESC_DTYPE)
+    order = [0, 1, 2, 3, 2, 0, 1]
+    for scale in (2.0 ** 40, 2.0 ** -45):
+        refs = np.zeros(len(order), dtype=nsbind.TERM_DTYPE)
+        big = np.zeros(len(order), dtype=nsbind.TERM_DTYPE)
+        for i, t in enumerate(order):
+            e = ent[t]
+            refs[i] = (0, e["count"], e["byte_off"], e["idf"], 1.0)
+            big[i] = (0, e["count"], e["byte_off"], np.float32(e["idf"]) * np.float32(scale), 1.0)
+        rc, h0, n0, f0 = nsbind.search_batch_raw(eng.ctx, qd, refs, 10)
+        assert rc == 0
+        rc, h1, n1, f1 = nsbind.search_batch_raw(eng.ctx, qd, big, 10)
+        assert rc == 0
+        np.testing.assert_array_equal(n0, n1)
+        np.testing.assert_array_equal(f0, f1)
+        for q in range(3):
+            n = int(n0[q])
+            np.testing.assert_array_equal(h0[q, :n]["doc"], h1[q, :n]["doc"])
+            np.testing.assert_array_equal((h0[q, :n]["score"] * np.float32(scale)).view(np.uint32), h1[q, :n]["score"].view(np.uint32))
+
+
 def test_many_terms_per_query(engines):
     """More scored terms than one wave-pass handles (64) and than the reference's expansion cap (40)."""
     g, eng, ora = engines("mid1")
