@@ -515,7 +515,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
             }
             wave_sync();
         }
-        if (ncand > (uint32_t)(CB / 2)) ncand = wave_shrink(cand, ncand, theta, K, lane);
+        if (ncand > (uint32_t)(CB - 64)) ncand = wave_shrink(cand, ncand, theta, K, lane);   // keep room for one more step of offers
 
         if (hi >= last_doc) break;
         if (Rf == 0 && d_cur >= d_end) break;

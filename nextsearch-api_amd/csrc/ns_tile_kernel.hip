@@ -277,7 +277,7 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
             }
         }
         wave_sync();
-        if (ncand > (uint32_t)(CB / 2)) ncand = wave_shrink(cand, ncand, theta, K, lane);
+        if (ncand > (uint32_t)(CB - 64)) ncand = wave_shrink(cand, ncand, theta, K, lane);   // keep room for one more step of offers
     }
 #undef NS_ISSUE
 #undef NS_ROUND_SIZE
