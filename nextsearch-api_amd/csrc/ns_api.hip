@@ -661,13 +661,13 @@ extern "C" int ns_batch_run(ns_batch* b, int timed) {
     uint64_t* sf = b->direct ? b->o_found : b->d_part_found;
     if (b->n_witems && b->variant == 0) {
         // auto mode: ONE launch; each wave picks the body that suits its item (DevWItem::whole bit 1)
-        dim3 grid((b->n_witems + 3) / 4), block(256);
+        dim3 grid((b->n_witems + 3) / 4), block(64 * kUscoreWavesPerBlock);
         // K <= 64: a 128-entry candidate buffer is enough (K + 64 appended per step at most) and its
         // smaller LDS footprint admits more workgroups per CU.  Groups of <= 16 terms (all but exotic
         // queries) run in the instantiation with 16-entry term tables; the rest in the 64-entry one.
 #define NS_U(CBV, TM, N, PTR)                                                                                      \
         {                                                                                                          \
-            dim3 g_(((N) + 3) / 4);                                                                                \
+            dim3 g_(((N) + kUscoreWavesPerBlock - 1) / kUscoreWavesPerBlock);                                     \
             if (and_mode) hipLaunchKernelGGL((k_uscore<512, 128, true, CBV, TM>), g_, block, 0, st, (PTR), (N), b->d_terms, b->d_segs, sh, sn, sf, b->K); \
             else hipLaunchKernelGGL((k_uscore<512, 128, false, CBV, TM>), g_, block, 0, st, (PTR), (N), b->d_terms, b->d_segs, sh, sn, sf, b->K);         \
         }

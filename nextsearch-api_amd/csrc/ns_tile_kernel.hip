@@ -332,12 +332,17 @@ __global__ void __launch_bounds__(256) k_tscore(const DevWItem* __restrict__ ite
 // TMAX: most terms a group may have in this instantiation (16: smaller term tables, 3 KB less LDS per
 // workgroup; 64: the general case, launched only when needed).  An 8-entry instantiation reaches 7
 // workgroups per CU (23.2 KB LDS, 69 VGPRs) and measured 1.5% slower: the kernel is VALU-bound.
+// Waves per workgroup of k_uscore.  The waves of a workgroup are independent (no barrier, private LDS
+// slices), but a workgroup's wave slots and LDS are only released when its LAST wave ends: with 4 items of
+// unequal length per workgroup ~12 % of the wave slots sat idle mid-kernel.  One item per workgroup.
+constexpr int kUscoreWavesPerBlock = 1;
+
 template <int HK, int FB, bool AND, int CB, int TMAX>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) k_uscore(const DevWItem* __restrict__ items, uint32_t n_items,
+__global__ void __launch_bounds__(64 * kUscoreWavesPerBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) k_uscore(const DevWItem* __restrict__ items, uint32_t n_items,
                                                 const DevTerm* __restrict__ terms, const DevSeg* __restrict__ segs,
                                                 Hit* __restrict__ out_hits, uint32_t* __restrict__ out_nhits,
                                                 uint64_t* __restrict__ out_found, uint32_t K) {
-    constexpr int WPB = 4;
+    constexpr int WPB = kUscoreWavesPerBlock;
     __shared__ __attribute__((aligned(16))) uint32_t s_tbl[WPB][2 * HK];                 // HK/2 buckets of 4 entries, or one 2*HK-doc tile
     __shared__ __attribute__((aligned(16))) float s_vals[WPB][FB];                       // driver body: one accumulator per foreign posting
     __shared__ __attribute__((aligned(16))) uint8_t s_mcnt[WPB][AND ? 2 * HK : 16];
