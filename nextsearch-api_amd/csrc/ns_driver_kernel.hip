@@ -81,8 +81,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
         end = tm.count;
         if (!(it.whole & 1u)) {
             const uint2* lst = seg.postings + tm.list_off;
-            cur = list_lower_bound(lst, tm.count, it.doc_lo);
-            end = list_lower_bound(lst, tm.count, it.doc_hi);
+            list_range(lst, tm.count, it.doc_lo, it.doc_hi, seg.n_docs, cur, end);
             if (end < cur) end = cur;
         }
         cur += base;   // absolute posting indices from here on

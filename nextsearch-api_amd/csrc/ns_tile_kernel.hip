@@ -60,8 +60,7 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
         end = tm.count;
         if (!(it.whole & 1u)) {
             const uint2* lst = seg.postings + tm.list_off;
-            cur = list_lower_bound(lst, tm.count, it.doc_lo);
-            end = list_lower_bound(lst, tm.count, it.doc_hi);
+            list_range(lst, tm.count, it.doc_lo, it.doc_hi, seg.n_docs, cur, end);
             if (end < cur) end = cur;
         }
         cur += (uint32_t)tm.list_off;

@@ -123,6 +123,40 @@ __device__ __forceinline__ uint32_t list_lower_bound(const uint2* lst, uint32_t 
     return lo;
 }
 
+// Both ends of a doc range in one list at once: the two binary searches advance in lockstep, so each
+// step has two independent loads in flight instead of one (the searches are pure HBM latency: ~20
+// dependent steps per end for a hot list, and every doc-range work item starts with them).
+// The first step of each search is an interpolation guess (lists are close to uniform in docId):
+// it usually cuts the bracket to a few hundred postings.
+__device__ __forceinline__ void list_range(const uint2* lst, uint32_t count, uint32_t doc_lo, uint32_t doc_hi, uint32_t n_docs,
+                                           uint32_t& first, uint32_t& last) {
+    uint32_t a0 = 0, b0 = count, a1 = 0, b1 = count;
+    if (count > 64u && n_docs > 0u) {
+        // guess +- a margin, checked by loading both bracket ends (4 independent loads)
+        const float dens = (float)count / (float)n_docs;
+        const uint32_t margin = 64u + (uint32_t)(8.0f * __builtin_sqrtf((float)count * (1.0f - (dens < 1.0f ? dens : 1.0f)) + 1.0f));
+        const uint32_t g0 = min(count, (uint32_t)((float)doc_lo * dens)), g1 = min(count, (uint32_t)((float)doc_hi * dens));
+        const uint32_t l0 = g0 > margin ? g0 - margin : 0u, h0 = min(count - 1u, g0 + margin);
+        const uint32_t l1 = g1 > margin ? g1 - margin : 0u, h1 = min(count - 1u, g1 + margin);
+        const uint32_t vl0 = lst[l0].x, vh0 = lst[h0].x, vl1 = lst[l1].x, vh1 = lst[h1].x;
+        // lower_bound(d) lies in (l, h] when lst[l] < d <= lst[h]
+        if (vl0 < doc_lo) a0 = l0 + 1u;
+        if (vh0 >= doc_lo) b0 = h0;
+        if (vl1 < doc_hi) a1 = l1 + 1u;
+        if (vh1 >= doc_hi) b1 = h1;
+        if (a0 > b0) { a0 = 0; b0 = count; }   // cannot happen for a sorted list
+        if (a1 > b1) { a1 = 0; b1 = count; }
+    }
+    while (a0 < b0 || a1 < b1) {
+        const uint32_t m0 = a0 + ((b0 - a0) >> 1), m1 = a1 + ((b1 - a1) >> 1);
+        const uint32_t v0 = lst[min(m0, count - 1u)].x, v1 = lst[min(m1, count - 1u)].x;
+        if (a0 < b0) { if (v0 < doc_lo) a0 = m0 + 1u; else b0 = m0; }
+        if (a1 < b1) { if (v1 < doc_hi) a1 = m1 + 1u; else b1 = m1; }
+    }
+    first = a0;
+    last = a1;
+}
+
 // DPP wave reductions (gfx9 row_shr / row_bcast forms): 6 VALU instructions, no LDS round trips.
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ uint32_t dpp_mov(uint32_t old, uint32_t src) {
