@@ -1,6 +1,7 @@
 #include "engine.hpp"
 
 #include <algorithm>
+#include <thread>
 #include <cmath>
 #include <limits>
 
@@ -78,12 +79,11 @@ bool Engine::reload() {
     return true;
 }
 
-void Engine::build_refs(const std::vector<std::string>& queries, std::vector<ns_query_desc>& qd,
-                        std::vector<ns_term_ref>& refs, std::vector<uint8_t>& usable) const {
-    qd.assign(queries.size(), ns_query_desc{0, 0});
-    usable.assign(queries.size(), 0);
-    refs.clear();
-    for (size_t q = 0; q < queries.size(); q++) {
+// Query preparation (tokenise, stop-words, lexicon probes, idf: src/api_engine.cpp:388-397,:454-461) for
+// queries [q0, q1); `refs` receives the term refs of those queries, qd[q].term_begin is relative to it.
+void Engine::build_refs_range(const std::vector<std::string>& queries, size_t q0, size_t q1, std::vector<ns_query_desc>& qd,
+                              std::vector<ns_term_ref>& refs, std::vector<uint8_t>& usable) const {
+    for (size_t q = q0; q < q1; q++) {
         std::vector<std::string> terms = base_terms(queries[q]);
         qd[q].term_begin = (uint32_t)refs.size();
         if (terms.empty() || segments.empty()) continue;   // src/api_engine.cpp:407
@@ -106,6 +106,33 @@ void Engine::build_refs(const std::vector<std::string>& queries, std::vector<ns_
             }
         }
         qd[q].term_count = (uint32_t)refs.size() - qd[q].term_begin;
+    }
+}
+
+// A batch is Q independent searches: large batches are prepared by several host
+// threads, each on a contiguous slice of the queries (the lexicons are read-only), and the slices'
+// term refs are concatenated in query order.
+void Engine::build_refs(const std::vector<std::string>& queries, std::vector<ns_query_desc>& qd,
+                        std::vector<ns_term_ref>& refs, std::vector<uint8_t>& usable) const {
+    const size_t Q = queries.size();
+    qd.assign(Q, ns_query_desc{0, 0});
+    usable.assign(Q, 0);
+    refs.clear();
+    unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+    nt = (unsigned)std::min<size_t>(nt, Q / 512);   // below ~512 queries per thread the spawn costs more than it saves
+    if (nt <= 1) { build_refs_range(queries, 0, Q, qd, refs, usable); return; }
+    std::vector<std::vector<ns_term_ref>> part(nt);
+    std::vector<std::thread> th;
+    for (unsigned i = 0; i < nt; i++)
+        th.emplace_back([&, i]() { build_refs_range(queries, Q * i / nt, Q * (i + 1) / nt, qd, part[i], usable); });
+    for (auto& t : th) t.join();
+    size_t total = 0;
+    for (auto& p : part) total += p.size();
+    refs.reserve(total);
+    for (unsigned i = 0; i < nt; i++) {
+        const uint32_t base = (uint32_t)refs.size();
+        for (size_t q = Q * i / nt; q < Q * (i + 1) / nt; q++) qd[q].term_begin += base;
+        refs.insert(refs.end(), part[i].begin(), part[i].end());
     }
 }
 

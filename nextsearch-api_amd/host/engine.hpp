@@ -60,6 +60,8 @@ public:
 
     // Query preparation only: flattened term refs in the C-ABI's layout.
     // usable[q] == 0 marks the early-return case (no base terms, or no segments).
+    void build_refs_range(const std::vector<std::string>& queries, size_t q0, size_t q1, std::vector<ns_query_desc>& qd,
+                          std::vector<ns_term_ref>& refs, std::vector<uint8_t>& usable) const;
     void build_refs(const std::vector<std::string>& queries, std::vector<ns_query_desc>& qd,
                     std::vector<ns_term_ref>& refs, std::vector<uint8_t>& usable) const;
     // Staged form used by bench.py: descriptors resident on the device, caller drives ns_batch_*.

@@ -201,6 +201,73 @@ def test_idf_outside_short_division_range_scales_exactly(engines):
             np.testing.assert_array_equal((h0[q, :n]["score"] * np.float32(scale)).view(np.uint32), h1[q, :n]["score"].view(np.uint32))
 
 
+def _np_bm25(seg_lists, refs_idx, idfs, weights, doc_len, avgdl):
+    """fp32 restatement of src/api_engine.cpp:477-480 in numpy (every operation rounds to fp32)."""
+    f = np.float32
+    acc = {}
+    for li, idf, w in zip(refs_idx, idfs, weights):
+        docs, tfs = seg_lists[li]
+        dl = doc_len[docs].astype(np.float32)
+        norm = f(1.2) * ((f(1.0) - f(0.75)) + f(0.75) * (dl / f(avgdl)))
+        tf = tfs.astype(np.float32)
+        s = (f(idf) * (tf * (f(1.2) + f(1.0)))) / (tf + norm)
+        x = f(w) * s
+        for d, v in zip(docs.tolist(), x.tolist()):
+            acc[d] = f(acc.get(d, f(0.0)) + f(v))
+    return acc
+
+
+def test_sparse_lists_over_20m_docs_span_clamp():
+    """A segment of 20 M docs with very sparse lists: one super-batch of the driver-stream body would
+    span more docs than a table entry can identify (2^23), so the kernel clamps the span and walks
+    through empty super-batches.  Checked against a numpy fp32 restatement through the raw C-ABI."""
+    L = nsbind.hip_lib()
+    ctx = C.c_void_p()
+    assert L.ns_ctx_create(0, C.byref(ctx)) == 0
+    N = 20_000_000
+    rng = np.random.default_rng(7)
+    doc_len = rng.integers(20, 5000, size=N, dtype=np.uint32)
+    avgdl = float(np.float32(doc_len.astype(np.float64).mean()))
+    sizes = [700, 150, 40, 2500, 9]
+    lists, payload = [], []
+    for n in sizes:
+        docs = np.sort(rng.choice(N, size=n, replace=False)).astype(np.uint32)
+        tfs = rng.integers(1, 9, size=n, dtype=np.uint32)
+        lists.append((docs, tfs))
+        payload.append(np.stack([docs, tfs], axis=1).astype(np.uint32).ravel())
+    # make lists 0 and 3 share docs so that accumulation across terms is exercised
+    share = lists[3][0][::5][:100]
+    docs0 = np.unique(np.concatenate([lists[0][0], share])).astype(np.uint32)
+    lists[0] = (docs0, rng.integers(1, 9, size=len(docs0), dtype=np.uint32))
+    payload[0] = np.stack(lists[0], axis=1).astype(np.uint32).ravel()
+    flat = np.concatenate(payload)
+    offs = np.cumsum([0] + [len(p) * 4 for p in payload])[:-1]
+    seg = C.c_void_p()
+    assert L.ns_segment_upload(ctx, 0, N, C.c_float(avgdl), doc_len.ctypes.data, flat.ctypes.data, flat.nbytes, C.byref(seg)) == 0, L.ns_last_error(ctx)
+    idfs = [3.5, 5.25, 7.0, 2.125, 9.5]
+    queries = [[0, 3], [3, 0, 1], [1, 2, 4], [4], [2, 0, 3, 1, 4, 0]]
+    qd = np.zeros(len(queries), dtype=nsbind.QDESC_DTYPE)
+    refs = []
+    for qi, q in enumerate(queries):
+        qd[qi] = (len(refs), len(q))
+        for li in q:
+            refs.append((0, len(lists[li][0]), int(offs[li]), idfs[li], 1.0 if li != 1 else 0.5))
+    refs = np.array(refs, dtype=nsbind.TERM_DTYPE)
+    for k in (10, 100):
+        rc, hits, nhits, found = nsbind.search_batch_raw(ctx, qd, refs, k)
+        assert rc == 0, L.ns_last_error(ctx)
+        for qi, q in enumerate(queries):
+            acc = _np_bm25(lists, q, [idfs[li] for li in q], [1.0 if li != 1 else 0.5 for li in q], doc_len, avgdl)
+            assert int(found[qi]) == len(acc)
+            order = sorted(acc.items(), key=lambda kv: (-float(kv[1]), kv[0]))[:k]
+            n = int(nhits[qi])
+            assert n == len(order)
+            assert [int(d) for d in hits[qi, :n]["doc"]] == [d for d, _ in order]
+            np.testing.assert_array_equal(hits[qi, :n]["score"].view(np.uint32), np.array([v for _, v in order], dtype=np.float32).view(np.uint32))
+    assert L.ns_segment_release(ctx, seg) == 0
+    L.ns_ctx_destroy(ctx)
+
+
 def test_many_terms_per_query(engines):
     """More scored terms than one wave-pass handles (64) and than the reference's expansion cap (40)."""
     g, eng, ora = engines("mid1")

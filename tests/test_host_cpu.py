@@ -154,6 +154,28 @@ def test_build_refs_layout(golden_index):
     eng.close()
 
 
+def test_build_refs_threaded_equals_per_query(golden_index):
+    """Batches of >= 1024 queries are prepared by several host threads on contiguous slices; the result
+    must be the concatenation, in query order, of what each query gives on its own."""
+    g, d, _ = golden_index("small2")
+    eng = nsbind.Engine(d, -1)
+    base = ["covid virus", "the of", "zzzz", "virus covid covid", "vaccine", "", "covid-19 in children"]
+    queries = [base[(i * 7 + i // 5) % len(base)] for i in range(3000)]
+    qd, refs, usable = eng.build_refs(queries)
+    single = {q: eng.build_refs([q]) for q in set(queries)}
+    pos = 0
+    for i, q in enumerate(queries):
+        sqd, srefs, su = single[q]
+        assert usable[i] == su[0] and qd["term_count"][i] == sqd["term_count"][0]
+        n = int(sqd["term_count"][0])
+        if n:
+            assert qd["term_begin"][i] == pos
+            assert refs[pos : pos + n].tobytes() == srefs[:n].tobytes()
+        pos += n
+    assert pos == len(refs)
+    eng.close()
+
+
 def test_generator_shapes():
     import tempfile
 
