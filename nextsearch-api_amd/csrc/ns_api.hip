@@ -40,8 +40,6 @@ struct ns_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    hipStream_t aux_stream[2] = {nullptr, nullptr};   // the three item classes are scored concurrently
-    hipEvent_t fork_ev = nullptr, join_ev[2] = {nullptr, nullptr};
     std::string err;
     std::string devname;
     int n_cus = 0;
@@ -172,16 +170,6 @@ extern "C" int ns_ctx_create(int device, ns_ctx** out) {
         return rc;
     }
     ctx->stream = ctx->own_stream;
-    for (int i = 0; i < 2 && e == hipSuccess; i++) {
-        e = hipStreamCreateWithFlags(&ctx->aux_stream[i], hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->join_ev[i], hipEventDisableTiming);
-    }
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming);
-    if (e != hipSuccess) {
-        int rc = fail(nullptr, NS_E_HIP, "stream/event creation: %s", hipGetErrorString(e));
-        ns_ctx_destroy(ctx);
-        return rc;
-    }
     *out = ctx;
     return NS_OK;
 }
@@ -197,11 +185,6 @@ extern "C" void ns_ctx_destroy(ns_ctx* ctx) {
         (void)hipFree(s->d_pnorm);
         delete s;
     }
-    for (int i = 0; i < 2; i++) {
-        if (ctx->aux_stream[i]) (void)hipStreamDestroy(ctx->aux_stream[i]);
-        if (ctx->join_ev[i]) (void)hipEventDestroy(ctx->join_ev[i]);
-    }
-    if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
