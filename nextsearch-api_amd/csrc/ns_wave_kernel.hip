@@ -81,8 +81,10 @@ __device__ __noinline__ uint64_t wave_shrink_packed(uint64_t* cand, uint32_t n, 
 }
 __device__ __forceinline__ uint32_t wave_shrink(uint64_t* cand, uint32_t n, float& theta, uint32_t K, int lane) {
     uint64_t r = wave_shrink_packed(cand, n, __float_as_uint(theta), K, lane);
-    theta = __uint_as_float((uint32_t)(r >> 32));
-    return (uint32_t)r;
+    // wave-uniform by construction; telling the compiler keeps theta, the candidate count and every
+    // decision that depends on them in SGPRs (scalar branches instead of exec-masked vector code)
+    theta = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(r >> 32)));
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r);
 }
 
 // ballot straight from the compare (HIP's __ballot goes through an int and costs two extra vector instructions)
