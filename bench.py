@@ -196,7 +196,6 @@ def main():
                 "k": K,
                 "parallelism": f"query-sharded x{n_gpus}, index replicated" + (", RCCL all-gather of results per step" if n_gpus > 1 else ""),
                 "kernel_variant": args.variant,
-                "tile_docs": info.tile_docs,
                 "work_items": info.n_items,
             },
             "roofline": {
