@@ -131,11 +131,13 @@ int  ns_batch_get_info(ns_batch* b, ns_batch_info* info);
 void ns_batch_destroy(ns_batch* b);
 
 /* ---- tuning knobs (per ctx; 0 = library default) --------------------------------------------- */
-/* variant: 0 = default; 5/6/7 = wave-private kernel with 256/512/1024-entry tables; 1..4 = the
- * workgroup-tile kernel (also the fallback for term groups of more than 64 terms); see DESIGN.md
- * "kernel variants".  min_items: number of work items below which queries are additionally split
- * across doc ranges.  split_postings: a (query, segment) group is split into doc ranges of about
- * this many postings each. */
+/* variant: 0 = default (k_uscore: every work item picks the driver-stream or the doc-tile body);
+ * 12..17 = driver-stream body for every group, 18..20 = doc-tile body for every group, 5..11 = the
+ * previous wave-private kernel, 1..4 = the workgroup-tile kernel (also the fallback for term groups
+ * of more than 64 terms); see DESIGN.md "Kernel variants" (all are parity-tested).  min_items: number
+ * of work items below which groups are additionally split across doc ranges.  split_postings: a
+ * (query, segment) group is split into doc ranges of about this much estimated work (variant 0: units
+ * of one streamed posting, default 98304 for K <= 32 and 262144 above; other variants: postings). */
 int  ns_set_tuning(ns_ctx* ctx, uint32_t variant, uint32_t min_items, uint32_t split_postings);
 
 #ifdef __cplusplus
