@@ -203,9 +203,11 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
                 }
                 s_cur += cnt;
                 if (cnt < n) {   // reached the end of the tile: the first posting not taken is the term's next doc
-#pragma unroll
-                    for (int j = 0; j < E; j++)
-                        if ((cnt >> 6) == (uint32_t)j) s_nd = rdlane(ps[j].x, cnt & 63u);   // uniform
+                    // select the chunk with two uniform v_cndmask levels, then ONE readlane
+                    const uint32_t jc = cnt >> 6;
+                    const uint32_t x01 = (jc & 1u) ? ps[1].x : ps[0].x;
+                    const uint32_t x23 = (jc & 1u) ? ps[3].x : ps[2].x;
+                    s_nd = rdlane((jc & 2u) ? x23 : x01, cnt & 63u);
                     break;
                 }
             }
