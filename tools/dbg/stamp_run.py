@@ -12,10 +12,9 @@ nsbind.gen_index(idx, 1, 1_000_000, 65536, 1337, False)
 eng = nsbind.Engine(idx, 0)
 eng.set_tuning(int(sys.argv[1]) if len(sys.argv) > 1 else 0, 0, 0)
 laws = law_bench.laws()
-names = ["0 setup", "1 wait probe->hi", "2 foreign load wait", "3 cursors", "4 foreign bm25", "5 claim", "6 elect owner",
-         "7 rmw before", "8 driver load wait", "9 driver bm25/take", "10 lookups", "11 private offers", "12 rmw after",
-         "13 read-back+offers", "14 shrink", "15 final"]
-for n in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["r1", "cfg5_1hot", "cfg5_2hot", "cfg5"]):
+names = ["0 setup", "1 term prologue", "2 round size + load issue", "3 (prefetch) + load wait", "4 masks+bm25+LDS reads", "5 LDS writes",
+         "6 round end / next-doc", "7 term epilogue", "8 next header", "9 read-back scan", "10 shrink/loop", "11 final"]
+for n in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["cfg5_tile"]):
     qs, k = laws[n]
     b = eng.prepare(qs, k)
     b.run(False); b.sync()
@@ -24,9 +23,9 @@ for n in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["r1", "cfg5_1hot", "
     b.run(True); b.sync()
     L.ns_debug_stamps(out, 1)
     inf = b.info()
-    tot = sum(out[i] for i in range(16)); waves = out[31]
-    nb = inf.postings / 256.0
-    print(f"{n}: kernel {inf.last_score_kernel_ms:.3f} ms, dscore waves {waves}, cycles/wave {tot/max(waves,1):.0f}, cycles per 256 postings {tot/nb:.0f}")
-    for i in range(16):
-        print(f"    {names[i]:>22}: {100.0*out[i]/tot:5.1f}%  ({out[i]/nb:8.0f} cyc/256)")
+    tot = sum(out[i] for i in range(12)); waves = out[31]
+    nb = inf.postings / 64.0
+    print(f"{n}: kernel {inf.last_score_kernel_ms:.3f} ms, tile-body waves {waves}, cycles per 64 postings {tot/nb:.0f}")
+    for i in range(12):
+        print(f"    {names[i]:>30}: {100.0*out[i]/tot:5.1f}%  ({out[i]/nb:8.0f} cyc/chunk)")
     b.close()
