@@ -103,6 +103,8 @@ static constexpr uint32_t kDefaultSplitPostings = 32768;   // forced variants: p
 // top-K warm-up and its K-row partial result, so large K wants fewer, longer items (sweeps: profiles/r01).
 static constexpr uint32_t kSplitWorkSmallK = 98304, kSplitWorkLargeK = 262144;
 static constexpr uint64_t kWorkForeign = 8, kWorkTile = 2;
+// per-item, per-term constants of the launch-order key (fitted to per-item timestamps, tools/dbg/item_times.py)
+static constexpr uint64_t kItemTermGeneral = 10000, kItemTermThin = 3000, kItemTermTile = 8000;
 
 template <int D, int HK>
 static void launch_wscore(bool and_mode, uint32_t n_items, hipStream_t st, const DevWItem* items, const DevTerm* terms,
@@ -512,7 +514,12 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                     if (it.doc_hi <= it.doc_lo) continue;
                     it.out_slot = n_rows++;
                     it.whole = (ns == 1 ? 1u : 0u) | (hg.fast_div ? 8u : 0u);
-                    witem_cost.push_back({hg.work / ns + 1, (uint32_t)witems.size()});
+                    {
+                        // launch-order key = estimated run time of the ITEM: its share of the group's work plus what
+                        // every item pays per term regardless of size (window planning, range searches, table set-up)
+                        const uint64_t per_term = hg.cls == 2 ? kItemTermTile : (hg.cls == 1 ? kItemTermThin : kItemTermGeneral);
+                        witem_cost.push_back({hg.work / ns + 1 + (ctx->variant == 0 ? per_term * hg.g.term_count : 0), (uint32_t)witems.size()});
+                    }
                     witem_cls.push_back(hg.cls);
                     witems.push_back(it);
                 }
