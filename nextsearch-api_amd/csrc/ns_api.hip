@@ -501,7 +501,10 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
             const DevSeg& sg = segs[hg.g.seg];
             if (sg.n_docs == 0) continue;   // empty segment: nothing to score
             if (hg.wave) {
-                uint64_t want = std::max<uint64_t>((hg.work + split_postings - 1) / split_postings, chunks_per_group);
+                // thin and tile groups run at a steady rate per posting: fewer, longer items (less per-item set-up,
+                // same balance); groups with dense foreign lists vary more per posting and stay finer
+                const uint64_t sp_ = (ctx->variant == 0 && hg.cls != 0) ? split_postings * 2 : split_postings;
+                uint64_t want = std::max<uint64_t>((hg.work + sp_ - 1) / sp_, chunks_per_group);
                 uint32_t ns = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want, 1), std::min<uint32_t>(sg.n_docs, 4096));
                 for (uint32_t i = 0; i < ns; i++) {
                     DevWItem it{};
