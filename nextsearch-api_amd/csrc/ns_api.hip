@@ -661,8 +661,8 @@ extern "C" int ns_batch_run(ns_batch* b, int timed) {
 #define NS_U(CBV, TM, N, PTR)                                                                                      \
         {                                                                                                          \
             dim3 g_(((N) + kUscoreWavesPerBlock - 1) / kUscoreWavesPerBlock);                                     \
-            if (and_mode) hipLaunchKernelGGL((k_uscore<512, 128, true, CBV, TM>), g_, block, 0, st, (PTR), (N), b->d_terms, b->d_segs, sh, sn, sf, b->K); \
-            else hipLaunchKernelGGL((k_uscore<512, 128, false, CBV, TM>), g_, block, 0, st, (PTR), (N), b->d_terms, b->d_segs, sh, sn, sf, b->K);         \
+            if (and_mode) hipLaunchKernelGGL((k_uscore<512, 192, true, CBV, TM>), g_, block, 0, st, (PTR), (N), b->d_terms, b->d_segs, sh, sn, sf, b->K); \
+            else hipLaunchKernelGGL((k_uscore<512, 192, false, CBV, TM>), g_, block, 0, st, (PTR), (N), b->d_terms, b->d_segs, sh, sn, sf, b->K);         \
         }
         const uint32_t n_narrow = b->n_class[0], n_wide = b->n_witems - b->n_class[0];
         (void)grid;
