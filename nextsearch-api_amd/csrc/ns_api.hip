@@ -74,7 +74,7 @@ static int fail(ns_ctx* ctx, int code, const char* fmt, ...) {
 //   workgroup, slots per thread, postings per thread per round; tile_docs = nt * spt.
 struct VariantDesc { uint32_t hb; uint32_t nt, spt, u; uint32_t d; };
 static const VariantDesc kVariants[] = {
-    {512, 512, 12, 4, 0},       // 0: default = AUTO: per (query, segment) group k_dscore<512,64> / k_dscore<512,256> / k_tscore<1024> by its mix of lists
+    {512, 512, 12, 4, 0},       // 0: default = AUTO: k_uscore, per (query, segment) group the driver-stream body (64 or 192 foreign postings per super-batch) or 1024-doc tiles, by its mix of lists
     {0, 1024, 12, 4, 0},        // 1: workgroup kernel, 12288-doc tiles
     {0, 512, 12, 4, 0},         // 2: workgroup kernel,  6144-doc tiles
     {0, 256, 16, 4, 0},         // 3: workgroup kernel,  4096-doc tiles

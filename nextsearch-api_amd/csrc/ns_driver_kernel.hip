@@ -29,14 +29,14 @@
 namespace ns {
 
 // NB  buckets of 4 entries per wave   FB  foreign postings per super-batch (<= 256: the owner index has 8 bits).
-// A driver lookup reads ONE bucket and stops unless the bucket is full and holds no match: with FB/NB <= 0.5
-// a full bucket is a 0.2% event, so practically every lookup is a single ds_read_b128 for all 64 lanes.
+// A driver lookup reads ONE bucket and stops unless the bucket is full and holds no match: with FB/NB <= 0.75
+// a full bucket is a < 1% event, so practically every lookup is a single ds_read_b128 for all 64 lanes.
 template <int NB, int FB, bool AND, int CB = 256>
 __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* __restrict__ terms, const DevSeg* __restrict__ segs,
                                             uint32_t* ent, float* vals, uint8_t* mcnt, uint64_t* cand, uint4* tab, uint32_t* aux,
                                             Hit* __restrict__ out_hits, uint32_t* __restrict__ out_nhits,
                                             uint64_t* __restrict__ out_found, uint32_t K, const int lane) {
-    // CB: candidate buffer entries, a power of two >= K + 64 (the launcher picks 128 for K <= 64: less LDS, one more workgroup per CU)
+    // CB: candidate buffer entries, a power of two >= K + 64 (the launcher picks 128 for K <= 64: less LDS)
     constexpr int FE = FB / 64;            // foreign postings per lane per super-batch
     constexpr int DE = 4;                  // driver postings per lane per round
     // entry = (0x8000 | tag) << 16 | home bucket << 8 | owner index; tag = the 15 docId bits above the bucket
