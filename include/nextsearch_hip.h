@@ -137,7 +137,7 @@ void ns_batch_destroy(ns_batch* b);
  * of more than 64 terms); see DESIGN.md "Kernel variants" (all are parity-tested).  min_items: number
  * of work items below which groups are additionally split across doc ranges.  split_postings: a
  * (query, segment) group is split into doc ranges of about this much estimated work (variant 0: units
- * of one streamed posting, default 98304 for K <= 32 and 262144 above; other variants: postings). */
+ * of one streamed posting, default 98304 for K <= 32 and 131072 above; other variants: postings). */
 int  ns_set_tuning(ns_ctx* ctx, uint32_t variant, uint32_t min_items, uint32_t split_postings);
 
 #ifdef __cplusplus

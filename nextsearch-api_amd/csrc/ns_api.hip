@@ -101,7 +101,7 @@ static constexpr uint32_t kWaveMaxTerms = 64;
 static constexpr uint32_t kDefaultSplitPostings = 32768;   // forced variants: postings per work item
 // auto mode: work units per item (one unit = one streamed driver posting).  Every item pays for its own
 // top-K warm-up and its K-row partial result, so large K wants fewer, longer items (sweeps: profiles/r01).
-static constexpr uint32_t kSplitWorkSmallK = 98304, kSplitWorkLargeK = 262144;
+static constexpr uint32_t kSplitWorkSmallK = 98304, kSplitWorkLargeK = 131072;
 static constexpr uint64_t kWorkForeign = 8, kWorkTile = 2;
 // per-item, per-term constants of the launch-order key (fitted to per-item timestamps, tools/dbg/item_times.py)
 static constexpr uint64_t kItemTermGeneral = 10000, kItemTermThin = 3000, kItemTermTile = 8000;
@@ -666,7 +666,7 @@ extern "C" int ns_batch_run(ns_batch* b, int timed) {
         }
         const uint32_t n_narrow = b->n_class[0], n_wide = b->n_witems - b->n_class[0];
         (void)grid;
-        if (b->K <= 64) {
+        if (b->K <= 32) {   // the buffer is shrunk to K when it holds more than CB - 64 entries: CB = 128 needs K well below 64
             if (n_narrow) NS_U(128, 16, n_narrow, b->d_witems);
             if (n_wide) NS_U(128, 64, n_wide, b->d_witems + n_narrow);
         } else {

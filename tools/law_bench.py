@@ -63,6 +63,8 @@ def laws():
     L["cfg5_1hot_gen"] = ([q for q in L["cfg5_1hot"][0] if cls_of(q) == "gen"], 10)
     L["cfg5_nohot_gen"] = ([q for q in L["cfg5_nohot"][0] if cls_of(q) == "gen"], 10)
     L["cfg3"] = (workloads.cfg3_queries(), 100)
+    L["cfg3_k10"] = (workloads.cfg3_queries(), 10)
+    L["cfg3_k64"] = (workloads.cfg3_queries(), 64)
     return L
 
 
