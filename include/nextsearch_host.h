@@ -34,6 +34,13 @@ uint32_t nsh_engine_num_segments(nsh_engine* e);
 const char* nsh_engine_segment_name(nsh_engine* e, uint32_t seg);
 int nsh_engine_segment_info(nsh_engine* e, uint32_t seg, uint32_t* n_docs, float* avgdl, uint64_t* n_postings,
                             uint32_t* n_terms, int* use_barrels);
+/* Result decoration from <index>/metadata.csv (src/api_engine.cpp:516-531, src/api_metadata.cpp): the
+ * decorated fields of one document, valid until close/reload; 1 if the document has a metadata row. */
+int nsh_engine_doc_metadata(nsh_engine* e, uint32_t seg, uint32_t doc, const char** title, const char** url,
+                            const char** publish_time, const char** author);
+/* Result assembly alone (src/api_engine.cpp:400-404,:505-536): JSON text for given hits; free with nsh_free. */
+int nsh_engine_hits_to_json(nsh_engine* e, const char* query, int k, int has_found, uint64_t found,
+                            const ns_hit* hits, uint32_t nhits, char** json_out);
 /* Host copies of what gets uploaded (valid until close/reload). */
 const uint32_t* nsh_engine_segment_doc_len(nsh_engine* e, uint32_t seg);
 const void* nsh_engine_segment_postings(nsh_engine* e, uint32_t seg, uint64_t* nbytes);

@@ -76,6 +76,8 @@ bool Engine::reload() {
     }
     seg_names = std::move(names);
     segments = std::move(loaded);
+    // metadata mapping (src/api_engine.cpp:110-113): absent file = no decoration, not an error
+    meta.load(index_dir / "metadata.csv", segments);
     return true;
 }
 
@@ -202,16 +204,22 @@ std::string Engine::to_json(const SearchResult& r) const {
         for (size_t i = 0; i < r.hits.size(); i++) {
             const SearchHit& h = r.hits[i];
             o += "    {\n";
+            // result decoration (src/api_engine.cpp:516-531): only non-empty fields; keys in nlohmann's (alphabetical) order
+            const nsx::MetaFields* md = meta.get(h.seg, h.doc);
+            if (md && !md->author.empty()) { o += "      \"author\": "; json_escape(o, md->author); o += ",\n"; }
             o += "      \"cord_uid\": ";
             const auto& seg = segments[h.seg];
             json_escape(o, h.doc < seg.cord_uid.size() ? seg.cord_uid[h.doc] : std::string());
             o += ",\n";
             o += "      \"docId\": " + std::to_string(h.doc) + ",\n";
+            if (md && !md->publish_time.empty()) { o += "      \"publish_time\": "; json_escape(o, md->publish_time); o += ",\n"; }
             o += "      \"score\": ";
             json_number_from_float(o, h.score);
             o += ",\n";
             o += "      \"segment\": ";
             json_escape(o, seg_names[h.seg]);
+            if (md && !md->title.empty()) { o += ",\n      \"title\": "; json_escape(o, md->title); }
+            if (md && !md->url.empty()) { o += ",\n      \"url\": "; json_escape(o, md->url); }
             o += "\n";
             o += (i + 1 < r.hits.size()) ? "    },\n" : "    }\n";
         }

@@ -10,8 +10,8 @@
 // What crosses the C-ABI (include/nextsearch_hip.h) to the MI355X kernels:
 //   posting traversal, BM25 term scores, accumulation, top-k, found   src/api_engine.cpp:441-504
 //
-// Out of scope here: the three LRU caches, metadata.csv decoration, semantic
-// expansion, autocomplete.  There is no CPU scoring path: without a device search*() fails.
+//   result decoration from metadata.csv (title, url, publish_time, author): src/api_engine.cpp:516-531
+// Out of scope here: the three LRU caches, semantic expansion, autocomplete.  There is no CPU scoring path: without a device search*() fails.
 #pragma once
 
 #include <cstdint>
@@ -20,6 +20,7 @@
 
 #include "../../include/nextsearch_hip.h"
 #include "index_format.hpp"
+#include "metadata.hpp"
 
 namespace nextsearch {
 
@@ -46,6 +47,7 @@ public:
     nsx::fs::path index_dir;
     std::vector<std::string> seg_names;
     std::vector<nsx::SegmentData> segments;
+    nsx::MetadataTable meta;   // <index>/metadata.csv, parsed once at reload() (src/api_engine.cpp:110-113,:516-531)
 
     // device < 0: host-only (index + query preparation; every search call fails loudly)
     explicit Engine(int device = 0);

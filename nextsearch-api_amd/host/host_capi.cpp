@@ -60,6 +60,37 @@ extern "C" const char* nsh_engine_segment_name(nsh_engine* e, uint32_t seg) {
     return (e && seg < e->eng.seg_names.size()) ? e->eng.seg_names[seg].c_str() : "";
 }
 
+// Result decoration (src/api_engine.cpp:516-531): the four fields of a document, valid until close/reload.
+// Returns 1 if the document has a metadata row, else 0 (all four then point to "").
+extern "C" int nsh_engine_doc_metadata(nsh_engine* e, uint32_t seg, uint32_t doc, const char** title, const char** url,
+                                       const char** publish_time, const char** author) {
+    static const char* kEmpty = "";
+    const nsx::MetaFields* m = e ? e->eng.meta.get(seg, doc) : nullptr;
+    if (title) *title = m ? m->title.c_str() : kEmpty;
+    if (url) *url = m ? m->url.c_str() : kEmpty;
+    if (publish_time) *publish_time = m ? m->publish_time.c_str() : kEmpty;
+    if (author) *author = m ? m->author.c_str() : kEmpty;
+    return m ? 1 : 0;
+}
+// JSON text of one result assembled from given hits (the decoration + serialisation step alone; no device needed).
+extern "C" int nsh_engine_hits_to_json(nsh_engine* e, const char* query, int k, int has_found, uint64_t found,
+                                       const ns_hit* hits, uint32_t nhits, char** json_out) {
+    if (!e || !json_out) return -1;
+    nextsearch::SearchResult r;
+    r.query = query ? query : "";
+    r.k = std::max(1, std::min(k, 100));
+    r.segments = (int)e->eng.segments.size();
+    r.has_found = has_found != 0;
+    r.found = found;
+    for (uint32_t i = 0; i < nhits; i++) r.hits.push_back(nextsearch::SearchHit{hits[i].score, hits[i].seg_id, hits[i].doc_id});
+    const std::string js = e->eng.to_json(r);
+    char* out = (char*)std::malloc(js.size() + 1);
+    if (!out) return -1;
+    std::memcpy(out, js.c_str(), js.size() + 1);
+    *json_out = out;
+    return 0;
+}
+
 extern "C" int nsh_engine_segment_info(nsh_engine* e, uint32_t seg, uint32_t* n_docs, float* avgdl, uint64_t* n_postings,
                                        uint32_t* n_terms, int* use_barrels) {
     if (!e || seg >= e->eng.segments.size()) return -1;

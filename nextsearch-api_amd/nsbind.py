@@ -60,7 +60,7 @@ HOST_SYMBOLS = [
     "nsh_engine_num_segments", "nsh_engine_segment_name", "nsh_engine_segment_info",
     "nsh_engine_segment_doc_len", "nsh_engine_segment_postings", "nsh_engine_lookup", "nsh_bm25_idf",
     "nsh_base_terms", "nsh_engine_build_refs", "nsh_engine_search_json", "nsh_free",
-    "nsh_engine_search_batch", "nsh_engine_prepare",
+    "nsh_engine_search_batch", "nsh_engine_prepare", "nsh_engine_doc_metadata", "nsh_engine_hits_to_json",
 ]
 
 _hip = None
@@ -137,6 +137,8 @@ def host_lib():
         L.nsh_free.restype = None
         L.nsh_engine_search_batch.argtypes = [vp, C.POINTER(C.c_char_p), u32, i32, u32, vp, vp, vp, vp]
         L.nsh_engine_prepare.argtypes = [vp, C.POINTER(C.c_char_p), u32, i32, u32, C.POINTER(vp)]
+        L.nsh_engine_doc_metadata.argtypes = [vp, u32, u32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]
+        L.nsh_engine_hits_to_json.argtypes = [vp, C.c_char_p, i32, i32, u64, vp, u32, C.POINTER(vp)]
         _host = L
     return _host
 
@@ -282,6 +284,26 @@ class Engine:
         if rc != 0:
             raise RuntimeError("nsh_engine_build_refs failed")
         return qd, refs[: n.value], usable
+
+    def doc_metadata(self, seg, doc):
+        """The decorated fields of one document (None if it has no metadata.csv row)."""
+        t, u, p, a = C.c_char_p(), C.c_char_p(), C.c_char_p(), C.c_char_p()
+        has = self._L.nsh_engine_doc_metadata(self.h, seg, doc, C.byref(t), C.byref(u), C.byref(p), C.byref(a))
+        if not has:
+            return None
+        return {"title": t.value.decode(), "url": u.value.decode(), "publish_time": p.value.decode(), "author": a.value.decode()}
+
+    def hits_to_json(self, query, k, has_found, found, hits):
+        """Result assembly alone: JSON text for given hits (numpy array of HIT_DTYPE)."""
+        hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+        out = C.c_void_p()
+        q = query.encode("utf-8") if isinstance(query, str) else query
+        rc = self._L.nsh_engine_hits_to_json(self.h, q, k, 1 if has_found else 0, int(found), hits.ctypes.data, len(hits), C.byref(out))
+        if rc != 0:
+            raise RuntimeError("nsh_engine_hits_to_json failed")
+        s = C.string_at(out).decode("utf-8")
+        self._L.nsh_free(out)
+        return s
 
     def search_json(self, query, k):
         out = C.c_void_p()

@@ -103,3 +103,57 @@ WORKLOADS = {
     "cfg4": (cfg4_queries, 4096, 10, 0, (8, 125_000)),
     "cfg5": (cfg5_queries, 16384, 10, 0, (1, 1_000_000)),
 }
+
+
+# ---- synthetic metadata.csv (CORD-19 column layout) for the result-decoration tests -----------------
+_META_HEADER = ("cord_uid,sha,source_x,title,doi,pmcid,pubmed_id,license,abstract,publish_time,authors,journal,"
+                "mag_id,who_covidence_id,arxiv_id,pdf_json_files,pmc_json_files,url,s2_id")
+_TITLES = ["Clinical features of patients", "A study, with commas, of viral load", 'The "quoted" outbreak', "",
+           "Café au lait spots — a review", "Tab\there and back\\slash", "Short", "  padded title  "]
+_AUTHORS = ["Smith, John; Doe, Jane", "John Smith", "(Zhang Wei) 张伟; Li, Na", " ; Doe, Jane", "Smith,", "",
+            "Madonna", "van der Berg, Anna;", "  García López, María  ; X, Y", "O'Neil, Pat"]
+_URLS = ["https://doi.org/10.1000/{i}; https://www.ncbi.nlm.nih.gov/pubmed/{i}/", "https://example.org/paper/{i}", "",
+         ";https://only-after-semicolon/{i}"]
+_DATES = ["2020-03-{d:02d}", "2020", "", "2019-12-31"]
+
+
+def _csv_field(s):
+    """Quote the way CORD-19's writer does: only when needed; embedded quotes are doubled."""
+    if any(c in s for c in ',"\n') or s != s.strip():
+        return '"' + s.replace('"', '""') + '"'
+    return s
+
+
+def metadata_csv(n_docs_total, seed=11):
+    """Deterministic CSV text (bytes) for documents u00000000 .. u{n_docs_total-1:08d}: ~70 % of the docs get a
+    row; plus duplicate cord_uids (first row wins), rows for unknown uids, a short (malformed) row, a row with an
+    empty cord_uid, a quoted field with an embedded newline (split by the line-based reader) and CRLF endings."""
+    rng = random.Random(seed)
+    lines = [_META_HEADER]
+    for i in range(n_docs_total):
+        if rng.random() < 0.3:
+            continue
+        t = _TITLES[rng.randrange(len(_TITLES))]
+        if t and rng.random() < 0.5:
+            t = f"{t} {i}"
+        row = [f"u{i:08d}", f"{rng.getrandbits(64):016x}", "PMC", t, f"10.1000/{i}", f"PMC{i}", str(i), "cc-by",
+               "Abstract text, with a comma." if rng.random() < 0.5 else "", _DATES[rng.randrange(len(_DATES))].format(d=1 + i % 28),
+               _AUTHORS[rng.randrange(len(_AUTHORS))], "Journal of Tests", "", "", "", f"document_parses/pdf_json/{i}.json", "",
+               _URLS[rng.randrange(len(_URLS))].format(i=i), str(1000 + i)]
+        line = ",".join(_csv_field(x) for x in row)
+        if rng.random() < 0.05:
+            line += "\r"   # CRLF ending: the \r stays in the last column
+        lines.append(line)
+        if rng.random() < 0.03:   # a later duplicate with other values: must be ignored
+            dup = list(row)
+            dup[3] = "DUPLICATE ROW " + str(i)
+            dup[10] = "Nobody, N"
+            lines.append(",".join(_csv_field(x) for x in dup))
+        if rng.random() < 0.02:
+            lines.append(f"zz{i:08d},,,Unknown document {i},,,,,,2021,Ghost G,,,,,,,http://nowhere/{i},")
+        if rng.random() < 0.01:
+            lines.append("")                       # short row (no cord_uid column content)
+            lines.append(",deadbeef,PMC,Row with an empty cord_uid,,,,,,2020,A B,,,,,,,http://x,")
+        if rng.random() < 0.01:
+            lines.append(f'yy{i:08d},,,"A title with an embedded\nnewline, inside quotes",,,,,,2020,"C, D",,,,,,,http://y/{i},')
+    return ("\n".join(lines) + "\n").encode("utf-8")

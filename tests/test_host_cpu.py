@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 import nsbind
+import workloads
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -173,6 +174,115 @@ def test_build_refs_threaded_equals_per_query(golden_index):
             assert refs[pos : pos + n].tobytes() == srefs[:n].tobytes()
         pos += n
     assert pos == len(refs)
+    eng.close()
+
+
+def _meta_index(tmp_path_factory):
+    """The meta1 fixture's index: generator output + the deterministic metadata.csv (own directory:
+    the other golden tests expect undecorated results)."""
+    import hashlib
+
+    from conftest import load_golden
+
+    g = load_golden("meta1")
+    p = g["params"]
+    d = str(tmp_path_factory.mktemp("idx_meta") / "index")
+    nsbind.gen_index(d, p["n_segments"], p["docs_per_segment"], p["vocab"], p["seed"], p["legacy"])
+    csv = workloads.metadata_csv(p["n_segments"] * p["docs_per_segment"], p["meta_seed"])
+    assert hashlib.sha256(csv).hexdigest() == g["metadata_csv_sha256"]
+    with open(os.path.join(d, "metadata.csv"), "wb") as f:
+        f.write(csv)
+    return g, d, csv
+
+
+def test_result_assembly_equals_reference_json_text(tmp_path_factory):
+    """decoration from metadata.csv + JSON layout.  The golden holds the REAL
+    reference's Engine::search(...).dump(2) text; feeding its hits to this repo's result assembly must
+    reproduce that text byte for byte (keys, indentation, escaping, float spelling, optional fields)."""
+    import json
+
+    g, d, _ = _meta_index(tmp_path_factory)
+    eng = nsbind.Engine(d, -1)
+    names = [eng.segment_name(s) for s in range(eng.num_segments)]
+    n = 0
+    for case in g["cases"]:
+        for q, text in zip(g["queries"], case["json"]):
+            j = json.loads(text)
+            hits = np.zeros(len(j["results"]), dtype=nsbind.HIT_DTYPE)
+            for i, r in enumerate(j["results"]):
+                hits[i] = (np.float32(r["score"]), names.index(r["segment"]), r["docId"])
+            mine = eng.hits_to_json(q, case["k"], "found" in j, j.get("found", 0), hits)
+            assert mine == text, f"query {q!r} k={case['k']}"
+            n += len(hits)
+    assert n > 40
+    eng.close()
+
+
+def test_metadata_table_equals_python_restatement(tmp_path_factory):
+    """Every document's decorated fields against an independent restatement of src/api_metadata.cpp's rules
+    (physical lines, quote toggling without escapes, last header column wins, first row per cord_uid wins,
+    url cut at ';', first_author_et_al)."""
+    g, d, csv = _meta_index(tmp_path_factory)
+
+    def split(line):
+        out, cur, inq = [], [], False
+        for ch in line:
+            if ch == '"':
+                inq = not inq
+            elif ch == "," and not inq:
+                out.append("".join(cur)); cur = []
+            else:
+                cur.append(ch)
+        out.append("".join(cur))
+        return out
+
+    ws = " \t\n\r\f\v"
+
+    def author(raw):
+        s = raw.strip(ws)
+        if not s:
+            return ""
+        first = s.split(";", 1)[0].strip(ws)
+        while first and (first[-1] == "," or first[-1] in ws):
+            first = first[:-1]
+        first = first.strip(ws)
+        if not first:
+            return ""
+        if first[0] == "(":
+            c = first.find(")")
+            if c > 1 and first[1:c].strip(ws):
+                first = first[1:c].strip(ws)
+        if "," in first:
+            sur = first.split(",", 1)[0].strip(ws)
+        else:
+            t = first.strip(ws)
+            k = max(t.rfind(" "), t.rfind("\t"))
+            sur = t if k < 0 else t[k + 1:].strip(ws)
+        return sur + " et al." if sur else ""
+
+    text = csv.decode("utf-8")
+    lines = text.split("\n")
+    if lines and lines[-1] == "":
+        lines.pop()
+    cols = split(lines[0])
+    idx = {name: max(i for i, c in enumerate(cols) if c == name) for name in ("cord_uid", "url", "publish_time", "authors", "title")}
+    want = {}
+    for line in lines[1:]:
+        r = split(line)
+        if len(r) <= idx["cord_uid"] or not r[idx["cord_uid"]] or r[idx["cord_uid"]] in want:
+            continue
+        get = lambda k: r[idx[k]] if len(r) > idx[k] else ""   # noqa: E731
+        want[r[idx["cord_uid"]]] = {"title": get("title"), "url": get("url").split(";", 1)[0], "publish_time": get("publish_time"),
+                                    "author": author(get("authors"))}
+    eng = nsbind.Engine(d, -1)
+    per = g["params"]["docs_per_segment"]
+    checked = 0
+    for s in range(eng.num_segments):
+        for doc in range(per):
+            uid = "u%08d" % (s * per + doc)
+            assert eng.doc_metadata(s, doc) == want.get(uid), uid
+            checked += uid in want
+    assert checked > 3000
     eng.close()
 
 

@@ -78,11 +78,60 @@ def generated_queries(vocab, seed):
     return qs
 
 
+META_FIXTURE = dict(n_segments=2, docs_per_segment=3000, vocab=2048, seed=1337, legacy=False, meta_seed=11)
+META_QUERIES = ["covid virus", "vaccine", "t000100 t000101 covid", "pandemic respiratory", "t000500", "the of", "",
+                "zzzzunknown", "t000300 t000020", "coronavirus patients infection", "t001000 t001001 t001002", "COVID-19 vaccine"]
+
+
+def run_ref_json(index_dir, queries, k, workdir):
+    """ref_driver json: the reference's own Engine::search(...).dump(2) per query."""
+    import subprocess
+    qpath = os.path.join(workdir, "queries_json.txt")
+    opath = os.path.join(workdir, "ref_json.txt")
+    with open(qpath, "w") as f:
+        f.write("\n".join(queries) + "\n")
+    subprocess.check_call([orc.REF_DRIVER, "json", index_dir, qpath, str(k), opath], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    data = open(opath, "rb").read()
+    out, pos = [], 0
+    while pos < len(data):
+        nl = data.index(b"\n", pos)
+        assert data[pos:pos + 2] == b"J "
+        n = int(data[pos + 2:nl])
+        out.append(data[nl + 1:nl + 1 + n].decode("utf-8"))
+        pos = nl + 1 + n + 1
+    return out[:len(queries)]
+
+
+def make_meta_fixture(outdir):
+    p = META_FIXTURE
+    tmp = tempfile.mkdtemp(prefix="ns_golden_")
+    try:
+        idx = os.path.join(tmp, "index")
+        nsbind.gen_index(idx, p["n_segments"], p["docs_per_segment"], p["vocab"], p["seed"], p["legacy"])
+        csv = workloads.metadata_csv(p["n_segments"] * p["docs_per_segment"], p["meta_seed"])
+        with open(os.path.join(idx, "metadata.csv"), "wb") as f:
+            f.write(csv)
+        cases = []
+        for k in (5, 1):
+            cases.append({"k": k, "json": run_ref_json(idx, META_QUERIES + [""], k, tmp)[:len(META_QUERIES)]})
+        fixture = {"name": "meta1", "params": p, "metadata_csv_sha256": hashlib.sha256(csv).hexdigest(), "queries": META_QUERIES,
+                   "cases": cases,
+                   "source": "cord19::Engine::search(...).dump(2) of /root/reference (g++ -O2, nlohmann/json 3.1.1), via oracle/_ref/ref_driver json"}
+        with open(os.path.join(outdir, "meta1.json"), "w") as f:
+            json.dump(fixture, f, separators=(",", ":"))
+        print("meta1 bytes", os.path.getsize(os.path.join(outdir, "meta1.json")))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     if not os.path.exists(orc.REF_DRIVER):
         sys.exit("oracle/_ref/ref_driver missing: run `make -C oracle ref` where /root/reference is mounted")
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
+    make_meta_fixture(outdir)
+    if len(sys.argv) > 1 and sys.argv[1] == "meta":
+        return
     for name, p in FIXTURES.items():
         tmp = tempfile.mkdtemp(prefix="ns_golden_")
         try:
