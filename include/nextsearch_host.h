@@ -61,6 +61,11 @@ int nsh_engine_build_refs(nsh_engine* e, const char* const* queries, uint32_t n_
 /* Engine::search(query, k) -> JSON text with the reference's keys; caller frees with nsh_free. */
 int  nsh_engine_search_json(nsh_engine* e, const char* query, int k, char** json_out);
 void nsh_free(void* p);
+/* A batch of searches straight to the /api/search JSON bodies (result assembly on several host threads):
+ * *text_out receives all bodies back to back (free with nsh_free); offsets[q] .. offsets[q+1] delimit body q
+ * (offsets has n_queries + 1 entries). */
+int  nsh_engine_search_batch_json(nsh_engine* e, const char* const* queries, uint32_t n_queries, int k,
+                                  char** text_out, uint64_t* offsets);
 /* Batch search through ns_search_batch.  hits: n_queries*K (K = clamp(k,1,100)). */
 int nsh_engine_search_batch(nsh_engine* e, const char* const* queries, uint32_t n_queries, int k, uint32_t flags,
                             ns_hit* hits, uint32_t* nhits, uint64_t* found, uint8_t* has_found);

@@ -230,6 +230,24 @@ std::string Engine::to_json(const SearchResult& r) const {
     return o;
 }
 
+bool Engine::search_batch_json(const std::vector<std::string>& queries, int k, std::vector<std::string>& out) {
+    std::vector<SearchResult> res;
+    if (!search_batch(queries, k, NS_FLAG_OR, res)) return false;
+    const size_t Q = res.size();
+    out.assign(Q, std::string());
+    unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+    nt = (unsigned)std::min<size_t>(nt, Q / 512);
+    if (nt <= 1) {
+        for (size_t q = 0; q < Q; q++) out[q] = to_json(res[q]);
+        return true;
+    }
+    std::vector<std::thread> th;
+    for (unsigned i = 0; i < nt; i++)
+        th.emplace_back([&, i]() { for (size_t q = Q * i / nt; q < Q * (i + 1) / nt; q++) out[q] = to_json(res[q]); });
+    for (auto& t : th) t.join();
+    return true;
+}
+
 std::string Engine::search(const std::string& query, int k) {
     SearchResult r;
     if (!search_hits(query, k, NS_FLAG_OR, r)) {

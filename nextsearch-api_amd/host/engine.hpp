@@ -70,6 +70,8 @@ public:
     bool prepare(const std::vector<std::string>& queries, int k, uint32_t flags, ns_batch** out);
 
     std::string to_json(const SearchResult& r) const;
+    // A batch of searches straight to the /api/search JSON bodies (result assembly on several host threads).
+    bool search_batch_json(const std::vector<std::string>& queries, int k, std::vector<std::string>& out);
     ns_ctx* ctx() const { return ctx_; }
     const std::string& last_error() const { return err_; }
 

@@ -170,6 +170,28 @@ extern "C" int nsh_engine_search_json(nsh_engine* e, const char* query, int k, c
     return 0;
 }
 
+// Batch of searches to JSON bodies: *text_out receives all bodies back to back (free with nsh_free),
+// offsets[q] .. offsets[q+1] delimit body q (offsets has n_queries + 1 entries).
+extern "C" int nsh_engine_search_batch_json(nsh_engine* e, const char* const* queries, uint32_t n_queries, int k,
+                                            char** text_out, uint64_t* offsets) {
+    if (!e || !text_out || !offsets) return -1;
+    std::vector<std::string> qs(queries, queries + n_queries), bodies;
+    if (!e->eng.search_batch_json(qs, k, bodies)) { e->err = e->eng.last_error(); return -1; }
+    size_t total = 0;
+    for (auto& b : bodies) total += b.size();
+    char* buf = (char*)std::malloc(total + 1);
+    if (!buf) return -1;
+    size_t pos = 0;
+    for (uint32_t q = 0; q < n_queries; q++) {
+        offsets[q] = pos;
+        std::memcpy(buf + pos, bodies[q].data(), bodies[q].size());
+        pos += bodies[q].size();
+    }
+    offsets[n_queries] = pos;
+    buf[pos] = 0;
+    *text_out = buf;
+    return 0;
+}
 extern "C" void nsh_free(void* p) { std::free(p); }
 
 extern "C" int nsh_engine_search_batch(nsh_engine* e, const char* const* queries, uint32_t n_queries, int k, uint32_t flags,

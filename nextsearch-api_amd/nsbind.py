@@ -60,7 +60,7 @@ HOST_SYMBOLS = [
     "nsh_engine_num_segments", "nsh_engine_segment_name", "nsh_engine_segment_info",
     "nsh_engine_segment_doc_len", "nsh_engine_segment_postings", "nsh_engine_lookup", "nsh_bm25_idf",
     "nsh_base_terms", "nsh_engine_build_refs", "nsh_engine_search_json", "nsh_free",
-    "nsh_engine_search_batch", "nsh_engine_prepare", "nsh_engine_doc_metadata", "nsh_engine_hits_to_json",
+    "nsh_engine_search_batch", "nsh_engine_prepare", "nsh_engine_doc_metadata", "nsh_engine_hits_to_json", "nsh_engine_search_batch_json",
 ]
 
 _hip = None
@@ -139,6 +139,7 @@ def host_lib():
         L.nsh_engine_prepare.argtypes = [vp, C.POINTER(C.c_char_p), u32, i32, u32, C.POINTER(vp)]
         L.nsh_engine_doc_metadata.argtypes = [vp, u32, u32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]
         L.nsh_engine_hits_to_json.argtypes = [vp, C.c_char_p, i32, i32, u64, vp, u32, C.POINTER(vp)]
+        L.nsh_engine_search_batch_json.argtypes = [vp, C.POINTER(C.c_char_p), u32, i32, C.POINTER(vp), vp]
         _host = L
     return _host
 
@@ -304,6 +305,20 @@ class Engine:
         s = C.string_at(out).decode("utf-8")
         self._L.nsh_free(out)
         return s
+
+    def search_batch_json(self, queries, k, decode=True):
+        """Batch of searches straight to the /api/search JSON bodies."""
+        Q = len(queries)
+        offs = np.zeros(Q + 1, dtype=np.uint64)
+        out = C.c_void_p()
+        rc = self._L.nsh_engine_search_batch_json(self.h, _cstr_array(queries), Q, k, C.byref(out), offs.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"search_batch_json failed: {self.error()}")
+        raw = C.string_at(out, int(offs[Q]))
+        self._L.nsh_free(out)
+        if not decode:
+            return raw, offs
+        return [raw[int(offs[q]):int(offs[q + 1])].decode("utf-8") for q in range(Q)]
 
     def search_json(self, query, k):
         out = C.c_void_p()

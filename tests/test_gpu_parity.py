@@ -162,6 +162,13 @@ def test_search_json_with_metadata_equals_reference_text(tmp_path_factory):
                 jm = json.loads(mine)
                 assert jm.get("found") == j.get("found") and sorted(r["score"] for r in jm["results"]) == sorted(scores)
     assert exact >= 12
+    # the batch entry point assembles the same bodies (on several threads for large batches)
+    qs = g["queries"] * 60
+    bodies = eng.search_batch_json(qs, 5)
+    assert len(bodies) == len(qs)
+    for q, body in zip(qs[: len(g["queries"])], bodies):
+        assert body == eng.search_json(q, 5)
+    assert bodies[len(g["queries"]):2 * len(g["queries"])] == bodies[: len(g["queries"])]
     eng.close()
 
 

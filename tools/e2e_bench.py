@@ -20,3 +20,16 @@ for rep in range(3):
     t6 = time.perf_counter(); eng.search_batch(qs, 10); t7 = time.perf_counter()
     print(f"rep {rep}: query prep (tokenise+lexicon+idf) {1e3*(t1-t0):.1f} ms | ns_search_batch (host->host) {1e3*(t2-t1):.1f} ms = {Q/(t2-t1):.0f} q/s | "
           f"prepare(incl. query prep) {1e3*(t3-t2):.1f} ms, run {1e3*(t4-t3):.2f} ms, fetch {1e3*(t5-t4):.2f} ms | facade search_batch {1e3*(t7-t6):.1f} ms = {Q/(t7-t6):.0f} q/s")
+# query TEXT in -> /api/search JSON bodies out (result assembly incl. metadata.csv decoration when the file is there)
+import workloads as _w  # noqa: E402
+with open(os.path.join(idx, "metadata.csv"), "wb") as f:
+    f.write(_w.metadata_csv(1_000_000, 11))
+eng.close()
+t0 = time.perf_counter(); eng = nsbind.Engine(idx, 0); t1 = time.perf_counter()
+print(f"Engine.reload with a {os.path.getsize(os.path.join(idx, 'metadata.csv')) >> 20} MB metadata.csv: {t1 - t0:.3f} s")
+eng.search_batch_json(qs[:64], 10)
+for rep in range(3):
+    t0 = time.perf_counter(); raw, offs = eng.search_batch_json(qs, 10, decode=False); t1 = time.perf_counter()
+    print(f"rep {rep}: facade search_batch_json (text in, decorated JSON bodies out, {len(raw) >> 20} MB) {1e3*(t1-t0):.1f} ms = {Q/(t1-t0):.0f} q/s")
+eng.close()
+
