@@ -115,6 +115,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
     const uint32_t last_doc = it.doc_hi - 1;   // host guarantees doc_hi > doc_lo and doc_hi <= n_docs
     float theta = -__builtin_inff();
     uint32_t ncand = 0;
+    uint32_t nsorted = 0;   // leading candidates already in descending order (left by the last shrink)
     uint32_t found_lane = 0;   // per-lane part of `found` (foreign docs)
     uint32_t found_s = 0;      // wave-uniform part (private driver postings)
     bool ge_mode = false;   // a shrink happened inside the current super-batch: ties with theta may still win on docId
@@ -128,7 +129,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
         if (mask_ != 0ull) {                                                                       \
             uint32_t n_ = (uint32_t)__popcll(mask_);                                               \
             if (ncand + n_ > (uint32_t)CB) {                                                       \
-                ncand = wave_shrink(cand, ncand, theta, K, lane);                                  \
+                ncand = wave_shrink_cb<CB>(cand, ncand, nsorted, theta, K, lane);                                  \
                 ge_mode = true;                                                                    \
                 qf_ = (cond) && ((scorev) >= theta);                                               \
                 mask_ = wballot(qf_);                                                              \
@@ -148,7 +149,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
         if (mask_ != 0ull) {                                                                       \
             uint32_t n_ = (uint32_t)__popcll(mask_);                                               \
             if (ncand + n_ > (uint32_t)CB) {                                                       \
-                ncand = wave_shrink(cand, ncand, theta, K, lane);                                  \
+                ncand = wave_shrink_cb<CB>(cand, ncand, nsorted, theta, K, lane);                                  \
                 ge_mode = true;                                                                    \
                 mask_ = (condm) & wballot((scorev) >= theta);                                      \
                 n_ = (uint32_t)__popcll(mask_);                                                    \
@@ -514,7 +515,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
             }
             wave_sync();
         }
-        if (ncand > (uint32_t)(CB - 64)) ncand = wave_shrink(cand, ncand, theta, K, lane);   // keep room for one more step of offers
+        if (ncand > (uint32_t)(CB - 64)) ncand = wave_shrink_cb<CB>(cand, ncand, nsorted, theta, K, lane);   // keep room for one more step of offers
 
         if (hi >= last_doc) break;
         if (Rf == 0 && d_cur >= d_end) break;
@@ -530,7 +531,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
 
     // ---- this item's top-K ----
     wave_sync();
-    ncand = wave_shrink(cand, ncand, theta, K, lane);
+    ncand = wave_shrink_cb<CB>(cand, ncand, nsorted, theta, K, lane);
     const uint32_t n = min(ncand, K);
     Hit* oh = out_hits + (uint64_t)it.out_slot * K;
     for (uint32_t i = lane; i < K; i += 64) {

@@ -71,6 +71,7 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
     const uint32_t last_doc = it.doc_hi - 1;   // host guarantees doc_hi > doc_lo and doc_hi <= n_docs
     float theta = -__builtin_inff();
     uint32_t ncand = 0;
+    uint32_t nsorted = 0;   // leading candidates already in descending order (left by the last shrink)
     uint32_t found_s = 0;   // wave-uniform count (popcounts of ballots)
     wave_sync();
 
@@ -265,7 +266,7 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
                     if (mask != 0ull) {
                         uint32_t n = (uint32_t)__popcll(mask);
                         if (ncand + n > (uint32_t)CB) {
-                            ncand = wave_shrink(cand, ncand, theta, K, lane);
+                            ncand = wave_shrink_cb<CB>(cand, ncand, nsorted, theta, K, lane);
                             ge_mode = true;
                             mask = scm[c] & wballot(vv[c] >= theta);
                             n = (uint32_t)__popcll(mask);
@@ -278,7 +279,7 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
             }
         }
         wave_sync();
-        if (ncand > (uint32_t)(CB - 64)) ncand = wave_shrink(cand, ncand, theta, K, lane);   // keep room for one more step of offers
+        if (ncand > (uint32_t)(CB - 64)) ncand = wave_shrink_cb<CB>(cand, ncand, nsorted, theta, K, lane);   // keep room for one more step of offers
     }
 #undef NS_ISSUE
 #undef NS_ROUND_SIZE
@@ -286,7 +287,7 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
 
     // ---- this item's top-K ----
     wave_sync();
-    ncand = wave_shrink(cand, ncand, theta, K, lane);
+    ncand = wave_shrink_cb<CB>(cand, ncand, nsorted, theta, K, lane);
     const uint32_t n = min(ncand, K);
     Hit* oh = out_hits + (uint64_t)it.out_slot * K;
     for (uint32_t i = lane; i < K; i += 64) {

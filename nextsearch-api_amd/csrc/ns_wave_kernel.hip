@@ -50,18 +50,32 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
 }
 
 // in-LDS bitonic sort (descending) of a[0..P), P a power of two, by ONE wave
-__device__ __forceinline__ void wave_bitonic_desc(uint64_t* a, uint32_t P, int lane) {
+__device__ __forceinline__ void wave_bitonic(uint64_t* a, uint32_t P, int lane, bool ascending) {
     for (uint32_t k = 2; k <= P; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
             for (uint32_t q = lane; q < (P >> 1); q += 64) {
                 uint32_t i = ((q & ~(j - 1)) << 1) | (q & (j - 1));
                 uint32_t p = i | j;
                 uint64_t x = a[i], y = a[p];
-                bool desc = (i & k) == 0;
+                bool desc = ((i & k) == 0) != ascending;
                 if (desc ? (x < y) : (x > y)) { a[i] = y; a[p] = x; }
             }
             wave_sync();
         }
+    }
+}
+__device__ __forceinline__ void wave_bitonic_desc(uint64_t* a, uint32_t P, int lane) { wave_bitonic(a, P, lane, false); }
+// a[0..P) is bitonic (here: a descending run followed by an ascending one): the last log2(P) stages of
+// the sorting network leave it sorted descending
+__device__ __forceinline__ void wave_bitonic_merge_desc(uint64_t* a, uint32_t P, int lane) {
+    for (uint32_t j = P >> 1; j > 0; j >>= 1) {
+        for (uint32_t q = lane; q < (P >> 1); q += 64) {
+            uint32_t i = ((q & ~(j - 1)) << 1) | (q & (j - 1));
+            uint32_t p = i | j;
+            uint64_t x = a[i], y = a[p];
+            if (x < y) { a[i] = y; a[p] = x; }
+        }
+        wave_sync();
     }
 }
 
@@ -79,12 +93,56 @@ __device__ __noinline__ uint64_t wave_shrink_packed(uint64_t* cand, uint32_t n, 
     }
     return ((uint64_t)theta_bits << 32) | n;
 }
+// The same for the 256-entry buffer (K > 32), where the buffer is shrunk every ~90 new candidates.
+// `sorted`: the first `sorted` entries are already in descending order (what the previous shrink
+// left; new candidates are appended behind them).  With 129..256 entries of which at most 128 are new,
+// only the new ones are sorted (128-entry network, ascending) and merged with the old run (8 stages
+// over 256): 44 compare-exchange steps per lane instead of 72.
+__device__ __noinline__ uint64_t wave_shrink_merge_packed(uint64_t* cand, uint32_t n, uint32_t sorted, uint32_t theta_bits, uint32_t K, int lane) {
+    if (sorted > 0 && sorted <= 128u && n > 128u && n - sorted <= 128u) {
+        const uint32_t nn = n - sorted;
+        uint64_t v0 = 0, v1 = 0;   // 0 = padding: sorts last descending, first ascending
+        if ((uint32_t)lane < nn) v0 = cand[sorted + lane];
+        if ((uint32_t)(64 + lane) < nn) v1 = cand[sorted + 64 + lane];
+        wave_sync();
+        for (uint32_t i = sorted + lane; i < 128u; i += 64) cand[i] = 0;
+        cand[128 + lane] = v0;
+        cand[192 + lane] = v1;
+        wave_sync();
+        wave_bitonic(cand + 128, 128, lane, true);
+        wave_bitonic_merge_desc(cand, 256, lane);
+    } else {
+        uint32_t P = 2;
+        while (P < n) P <<= 1;
+        for (uint32_t i = n + lane; i < P; i += 64) cand[i] = 0;   // padding sorts last
+        wave_sync();
+        wave_bitonic_desc(cand, P, lane);
+    }
+    if (n >= K) {
+        theta_bits = __float_as_uint(unorder_bits((uint32_t)(cand[K - 1] >> 32)));
+        n = K;
+    }
+    return ((uint64_t)theta_bits << 32) | n;
+}
 __device__ __forceinline__ uint32_t wave_shrink(uint64_t* cand, uint32_t n, float& theta, uint32_t K, int lane) {
     uint64_t r = wave_shrink_packed(cand, n, __float_as_uint(theta), K, lane);
     // wave-uniform by construction; telling the compiler keeps theta, the candidate count and every
     // decision that depends on them in SGPRs (scalar branches instead of exec-masked vector code)
     theta = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(r >> 32)));
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r);
+}
+// CB-aware form used by the scoring bodies: the merge variant (and its `sorted` bookkeeping) exists only in
+// the 256-entry instantiations; `sorted` is updated to the new count (a shrink leaves a descending run)
+template <int CB>
+__device__ __forceinline__ uint32_t wave_shrink_cb(uint64_t* cand, uint32_t n, uint32_t& sorted, float& theta, uint32_t K, int lane) {
+    if constexpr (CB > 128) {
+        uint64_t r = wave_shrink_merge_packed(cand, n, sorted, __float_as_uint(theta), K, lane);
+        theta = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(r >> 32)));
+        sorted = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r);
+        return sorted;
+    } else {
+        return wave_shrink(cand, n, theta, K, lane);
+    }
 }
 
 // ballot straight from the compare (HIP's __ballot goes through an int and costs two extra vector instructions)
