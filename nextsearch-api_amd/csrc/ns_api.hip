@@ -37,6 +37,11 @@ struct ns_seg {
 };
 
 struct ns_ctx {
+    // Device blocks of destroyed batches are kept for the next batch (a serving loop prepares batch after batch
+    // of similar shape; 14 hipMalloc + 14 hipFree per batch cost more than the descriptors' upload).
+    struct Block { void* p; size_t n; };
+    std::vector<Block> pool;
+    size_t pool_bytes = 0;
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -187,6 +192,7 @@ extern "C" void ns_ctx_destroy(ns_ctx* ctx) {
         (void)hipFree(s->d_pnorm);
         delete s;
     }
+    for (auto& blk : ctx->pool) (void)hipFree(blk.p);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -354,26 +360,60 @@ struct ns_batch {
     float last_score_ms = -1.0f, last_total_ms = -1.0f;
     double sum_score_ms = 0.0, sum_total_ms = 0.0;
     uint32_t timed_runs = 0;
+    std::vector<std::pair<void*, size_t>> blocks;   // every device block of this batch (returned to the ctx pool on destroy)
 };
+
+static constexpr size_t kPoolMaxBytes = 1ull << 30;   // cached blocks beyond this are released
+
+static hipError_t pool_alloc(ns_ctx* ctx, void** out, size_t n) {
+    n = (std::max<size_t>(n, 1) + 255) & ~(size_t)255;
+    size_t best = (size_t)-1;
+    for (size_t i = 0; i < ctx->pool.size(); i++)
+        if (ctx->pool[i].n >= n && ctx->pool[i].n <= 2 * n + 4096 && (best == (size_t)-1 || ctx->pool[i].n < ctx->pool[best].n)) best = i;
+    if (best != (size_t)-1) {
+        *out = ctx->pool[best].p;
+        ctx->pool_bytes -= ctx->pool[best].n;
+        ctx->pool[best] = ctx->pool.back();
+        ctx->pool.pop_back();
+        return hipSuccess;
+    }
+    hipError_t e = hipMalloc(out, n);
+    if (e == hipErrorOutOfMemory && !ctx->pool.empty()) {   // give the cache back and try once more
+        for (auto& b : ctx->pool) (void)hipFree(b.p);
+        ctx->pool.clear(); ctx->pool_bytes = 0;
+        e = hipMalloc(out, n);
+    }
+    return e;
+}
+// caller has synchronised the stream: nothing in flight uses the block
+static void pool_free(ns_ctx* ctx, void* p, size_t n) {
+    if (!p) return;
+    n = (std::max<size_t>(n, 1) + 255) & ~(size_t)255;
+    if (ctx->pool_bytes + n > kPoolMaxBytes || ctx->pool.size() >= 64) { (void)hipFree(p); return; }
+    ctx->pool.push_back({p, n});
+    ctx->pool_bytes += n;
+}
 
 extern "C" void ns_batch_destroy(ns_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
-    (void)hipFree(b->d_items); (void)hipFree(b->d_witems); (void)hipFree(b->d_terms); (void)hipFree(b->d_groups);
-    (void)hipFree(b->d_queries); (void)hipFree(b->d_segs); (void)hipFree(b->d_bounds); (void)hipFree(b->d_part_hits);
-    (void)hipFree(b->d_part_nhits); (void)hipFree(b->d_part_found); (void)hipFree(b->d_heads); (void)hipFree(b->d_hits);
-    (void)hipFree(b->d_nhits); (void)hipFree(b->d_found);
+    for (auto& blk : b->blocks) pool_free(b->ctx, blk.first, blk.second);   // the stream is idle: safe to hand on
     for (auto& e : b->ev_pool) if (e) (void)hipEventDestroy(e);
     delete b;
 }
 
+static hipError_t batch_alloc(ns_batch* b, void** dptr, size_t n) {
+    hipError_t e = pool_alloc(b->ctx, dptr, n);
+    if (e == hipSuccess) b->blocks.push_back({*dptr, n});
+    return e;
+}
 template <class T>
-static hipError_t dev_upload(T** dptr, const std::vector<T>& v) {
+static hipError_t dev_upload(ns_batch* b, T** dptr, const std::vector<T>& v) {
     size_t n = std::max<size_t>(v.size(), 1) * sizeof(T);
-    hipError_t e = hipMalloc((void**)dptr, n);
+    hipError_t e = batch_alloc(b, (void**)dptr, n);
     if (e != hipSuccess) return e;
-    if (!v.empty()) e = hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    if (!v.empty()) e = hipMemcpyAsync(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, b->ctx->stream);
     return e;
 }
 
@@ -594,23 +634,24 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
 
     hipError_t e = hipSuccess;
     auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-    chk(dev_upload(&b->d_items, sorted_items));
-    chk(dev_upload(&b->d_witems, sorted_witems));
-    chk(dev_upload(&b->d_terms, dterms));
-    chk(dev_upload(&b->d_groups, bgroups));
-    chk(dev_upload(&b->d_queries, dq));
-    chk(dev_upload(&b->d_segs, segs));
-    chk(hipMalloc((void**)&b->d_bounds, std::max<uint64_t>(bounds_total, 1) * 4));
+    chk(dev_upload(b, &b->d_items, sorted_items));
+    chk(dev_upload(b, &b->d_witems, sorted_witems));
+    chk(dev_upload(b, &b->d_terms, dterms));
+    chk(dev_upload(b, &b->d_groups, bgroups));
+    chk(dev_upload(b, &b->d_queries, dq));
+    chk(dev_upload(b, &b->d_segs, segs));
+    chk(batch_alloc(b, (void**)&b->d_bounds, std::max<uint64_t>(bounds_total, 1) * 4));
     const size_t Qn = std::max<uint32_t>(n_queries, 1), Pn = std::max<uint32_t>(b->n_parts, 1);
-    chk(hipMalloc((void**)&b->d_hits, Qn * k * sizeof(Hit)));
-    chk(hipMalloc((void**)&b->d_nhits, Qn * 4));
-    chk(hipMalloc((void**)&b->d_found, Qn * 8));
+    chk(batch_alloc(b, (void**)&b->d_hits, Qn * k * sizeof(Hit)));
+    chk(batch_alloc(b, (void**)&b->d_nhits, Qn * 4));
+    chk(batch_alloc(b, (void**)&b->d_found, Qn * 8));
     if (!direct) {
-        chk(hipMalloc((void**)&b->d_part_hits, Pn * k * sizeof(Hit)));
-        chk(hipMalloc((void**)&b->d_part_nhits, Pn * 4));
-        chk(hipMalloc((void**)&b->d_part_found, Pn * 8));
-        chk(hipMalloc((void**)&b->d_heads, Pn * 4));
+        chk(batch_alloc(b, (void**)&b->d_part_hits, Pn * k * sizeof(Hit)));
+        chk(batch_alloc(b, (void**)&b->d_part_nhits, Pn * 4));
+        chk(batch_alloc(b, (void**)&b->d_part_found, Pn * 8));
+        chk(batch_alloc(b, (void**)&b->d_heads, Pn * 4));
     }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // the uploads read host vectors that die with this call
     if (e != hipSuccess) {
         int rc = fail(ctx, e == hipErrorOutOfMemory ? NS_E_NOMEM : NS_E_HIP, "ns_batch_prepare: %s", hipGetErrorString(e));
         ns_batch_destroy(b);
