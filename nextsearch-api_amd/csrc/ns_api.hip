@@ -520,8 +520,17 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
     // than ~split_postings units of estimated work (the longest item bounds the batch's tail; launch
     // order is longest-estimated-work first), and (b) so that a small batch still fills the chip.  Partial rows of one query are contiguous; k_merge joins them.
     const uint32_t min_items = ctx->min_items ? ctx->min_items : (uint32_t)std::max(ctx->n_cus, 1) * 8u;
-    const uint64_t split_postings = ctx->split_postings ? ctx->split_postings
-                                    : (ctx->variant != 0 ? kDefaultSplitPostings : (k <= 32 ? kSplitWorkSmallK : kSplitWorkLargeK));
+    uint64_t split_postings = ctx->split_postings ? ctx->split_postings
+                              : (ctx->variant != 0 ? kDefaultSplitPostings : (k <= 32 ? kSplitWorkSmallK : kSplitWorkLargeK));
+    if (!ctx->split_postings && ctx->variant == 0) {
+        // a small batch: cut finer so that the chip still sees ~100 items per CU (an item of the default size
+        // runs 0.3-1.3 ms: with fewer items than wave slots that would be the whole batch's time), but not
+        // below ~16 K units, where an item's fixed cost takes over
+        uint64_t total_work = 0;
+        for (const HostGroup& hg : groups) total_work += hg.work;
+        const uint64_t fine = total_work / ((uint64_t)std::max(ctx->n_cus, 1) * 96u);
+        split_postings = std::min<uint64_t>(split_postings, std::max<uint64_t>(fine, 16384));
+    }
     const uint32_t G = (uint32_t)groups.size();
     uint32_t chunks_per_group = 1;
     if (G > 0 && G < min_items) chunks_per_group = (min_items + G - 1) / G;

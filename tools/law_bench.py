@@ -64,6 +64,10 @@ def laws():
     L["cfg5_nohot_gen"] = ([q for q in L["cfg5_nohot"][0] if cls_of(q) == "gen"], 10)
     L["cfg3"] = (workloads.cfg3_queries(), 100)
     L["cfg3_k10"] = (workloads.cfg3_queries(), 10)
+    L["cfg5_seed7"] = (workloads.cfg5_queries(16384, 7), 10)
+    L["cfg5_seed99_q32768"] = (workloads.cfg5_queries(32768, 99), 10)
+    L["cfg5_q4096"] = (workloads.cfg5_queries(4096, 2005), 10)
+    L["cfg5_q1024"] = (workloads.cfg5_queries(1024, 2005), 10)
     L["cfg3_k64"] = (workloads.cfg3_queries(), 64)
     return L
 
