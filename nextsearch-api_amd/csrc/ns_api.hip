@@ -519,7 +519,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
     // ---- work items.  A group is split into doc ranges (a) so that no single worker carries more
     // than ~split_postings units of estimated work (the longest item bounds the batch's tail; launch
     // order is longest-estimated-work first), and (b) so that a small batch still fills the chip.  Partial rows of one query are contiguous; k_merge joins them.
-    const uint32_t min_items = ctx->min_items ? ctx->min_items : (uint32_t)std::max(ctx->n_cus, 1) * 8u;
+    const uint32_t min_items = ctx->min_items ? ctx->min_items : (uint32_t)std::max(ctx->n_cus, 1) * 24u;
     uint64_t split_postings = ctx->split_postings ? ctx->split_postings
                               : (ctx->variant != 0 ? kDefaultSplitPostings : (k <= 32 ? kSplitWorkSmallK : kSplitWorkLargeK));
     if (!ctx->split_postings && ctx->variant == 0) {
@@ -533,7 +533,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
     }
     const uint32_t G = (uint32_t)groups.size();
     uint32_t chunks_per_group = 1;
-    if (G > 0 && G < min_items) chunks_per_group = (min_items + G - 1) / G;
+    if (G > 0 && G < min_items) chunks_per_group = std::min<uint32_t>((min_items + G - 1) / G, 1024u);   // one query alone: 1024 ranges are plenty
     struct Cost { uint64_t c; uint32_t idx; };
     std::vector<DevItem> items;
     std::vector<DevWItem> witems;

@@ -65,6 +65,9 @@ def laws():
     L["cfg3"] = (workloads.cfg3_queries(), 100)
     L["cfg3_k10"] = (workloads.cfg3_queries(), 10)
     L["cfg5_seed7"] = (workloads.cfg5_queries(16384, 7), 10)
+    for nq in (1, 8, 64, 256):
+        L[f"cfg5_q{nq}"] = (workloads.cfg5_queries(256, 2005)[:nq], 10)
+    L["hot5_q1"] = ([" ".join(T(r) for r in (1, 2, 3, 4, 5))], 10)
     L["cfg5_seed99_q32768"] = (workloads.cfg5_queries(32768, 99), 10)
     L["cfg5_q4096"] = (workloads.cfg5_queries(4096, 2005), 10)
     L["cfg5_q1024"] = (workloads.cfg5_queries(1024, 2005), 10)
