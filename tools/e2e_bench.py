@@ -27,6 +27,11 @@ with open(os.path.join(idx, "metadata.csv"), "wb") as f:
 eng.close()
 t0 = time.perf_counter(); eng = nsbind.Engine(idx, 0); t1 = time.perf_counter()
 print(f"Engine.reload with a {os.path.getsize(os.path.join(idx, 'metadata.csv')) >> 20} MB metadata.csv: {t1 - t0:.3f} s")
+t0 = time.perf_counter()
+for q in qs[:500]:
+    eng.search_json(q, 10)
+t1 = time.perf_counter()
+print(f"one query at a time, Engine::search(query, 10) -> decorated JSON text: {1e6 * (t1 - t0) / 500:.0f} us per query (mean of 500)")
 eng.search_batch_json(qs[:64], 10)
 for rep in range(3):
     t0 = time.perf_counter(); raw, offs = eng.search_batch_json(qs, 10, decode=False); t1 = time.perf_counter()
