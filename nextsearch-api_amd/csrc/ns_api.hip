@@ -52,6 +52,14 @@ struct ns_ctx {
     uint32_t variant = 0;
     uint32_t min_items = 0;
     uint32_t split_postings = 0;
+    // Pinned staging: a batch's descriptor arrays go up in ONE copy and its three result arrays come down in
+    // ONE copy (a lone query is otherwise dominated by ten small pageable copies and the syncs they imply).
+    void* h_up = nullptr;
+    size_t h_up_cap = 0;
+    hipEvent_t up_done = nullptr;   // recorded after the upload that reads h_up; waited on before h_up is rewritten
+    bool up_busy = false;
+    void* h_down = nullptr;
+    size_t h_down_cap = 0;
 };
 
 static thread_local std::string g_create_err;
@@ -193,6 +201,9 @@ extern "C" void ns_ctx_destroy(ns_ctx* ctx) {
         delete s;
     }
     for (auto& blk : ctx->pool) (void)hipFree(blk.p);
+    if (ctx->h_up) (void)hipHostFree(ctx->h_up);
+    if (ctx->h_down) (void)hipHostFree(ctx->h_down);
+    if (ctx->up_done) (void)hipEventDestroy(ctx->up_done);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -360,10 +371,14 @@ struct ns_batch {
     float last_score_ms = -1.0f, last_total_ms = -1.0f;
     double sum_score_ms = 0.0, sum_total_ms = 0.0;
     uint32_t timed_runs = 0;
+    uint32_t* d_wide_q = nullptr;
+    uint32_t n_wide_q = 0;
+    size_t out_span = 0, off_nhits = 0, off_found = 0;   // [d_hits .. d_found end) is one contiguous span of the block
     std::vector<std::pair<void*, size_t>> blocks;   // every device block of this batch (returned to the ctx pool on destroy)
 };
 
 static constexpr size_t kPoolMaxBytes = 1ull << 30;   // cached blocks beyond this are released
+static constexpr size_t kStageMaxBytes = 256ull << 20;   // larger batches upload/fetch array by array
 
 static hipError_t pool_alloc(ns_ctx* ctx, void** out, size_t n) {
     n = (std::max<size_t>(n, 1) + 255) & ~(size_t)255;
@@ -408,15 +423,6 @@ static hipError_t batch_alloc(ns_batch* b, void** dptr, size_t n) {
     if (e == hipSuccess) b->blocks.push_back({*dptr, n});
     return e;
 }
-template <class T>
-static hipError_t dev_upload(ns_batch* b, T** dptr, const std::vector<T>& v) {
-    size_t n = std::max<size_t>(v.size(), 1) * sizeof(T);
-    hipError_t e = batch_alloc(b, (void**)dptr, n);
-    if (e != hipSuccess) return e;
-    if (!v.empty()) e = hipMemcpyAsync(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, b->ctx->stream);
-    return e;
-}
-
 extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const ns_term_ref* terms, uint32_t n_queries,
                                 uint32_t k, uint32_t flags, ns_batch** out) {
     if (!ctx) return fail(nullptr, NS_E_INVAL, "ns_batch_prepare: ctx is NULL");
@@ -641,26 +647,95 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
     b->postings = postings_total;
     b->direct = direct;
 
+    // One device block per batch: [descriptors, uploaded in one copy][scratch][hits | nhits | found, fetched in one copy]
     hipError_t e = hipSuccess;
     auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-    chk(dev_upload(b, &b->d_items, sorted_items));
-    chk(dev_upload(b, &b->d_witems, sorted_witems));
-    chk(dev_upload(b, &b->d_terms, dterms));
-    chk(dev_upload(b, &b->d_groups, bgroups));
-    chk(dev_upload(b, &b->d_queries, dq));
-    chk(dev_upload(b, &b->d_segs, segs));
-    chk(batch_alloc(b, (void**)&b->d_bounds, std::max<uint64_t>(bounds_total, 1) * 4));
+    size_t off = 0;
+    auto place = [&](size_t bytes) { const size_t o = off; off = (off + std::max<size_t>(bytes, 1) + 255) & ~(size_t)255; return o; };
     const size_t Qn = std::max<uint32_t>(n_queries, 1), Pn = std::max<uint32_t>(b->n_parts, 1);
-    chk(batch_alloc(b, (void**)&b->d_hits, Qn * k * sizeof(Hit)));
-    chk(batch_alloc(b, (void**)&b->d_nhits, Qn * 4));
-    chk(batch_alloc(b, (void**)&b->d_found, Qn * 8));
+    const size_t o_items = place(sorted_items.size() * sizeof(sorted_items[0]));
+    const size_t o_witems = place(sorted_witems.size() * sizeof(sorted_witems[0]));
+    const size_t o_terms = place(dterms.size() * sizeof(dterms[0]));
+    const size_t o_groups = place(bgroups.size() * sizeof(bgroups[0]));
+    const size_t o_queries = place(dq.size() * sizeof(dq[0]));
+    const size_t o_segs = place(segs.size() * sizeof(segs[0]));
+    std::vector<uint32_t> wide_q;   // queries cut into many partial rows: joined by k_merge_wide, one workgroup each
+    if (!direct)
+        for (uint32_t q = 0; q < n_queries; q++)
+            if (merge_is_wide(dq[q].part_count, k)) wide_q.push_back(q);
+    b->n_wide_q = (uint32_t)wide_q.size();
+    const size_t o_wideq = place(wide_q.size() * 4);
+    const size_t up_bytes = off;
+    const size_t o_bounds = place(bounds_total * 4);
+    size_t o_phits = 0, o_pnhits = 0, o_pfound = 0, o_heads = 0;
     if (!direct) {
-        chk(batch_alloc(b, (void**)&b->d_part_hits, Pn * k * sizeof(Hit)));
-        chk(batch_alloc(b, (void**)&b->d_part_nhits, Pn * 4));
-        chk(batch_alloc(b, (void**)&b->d_part_found, Pn * 8));
-        chk(batch_alloc(b, (void**)&b->d_heads, Pn * 4));
+        o_phits = place(Pn * k * sizeof(Hit));
+        o_pnhits = place(Pn * 4);
+        o_pfound = place(Pn * 8);
+        o_heads = place(Pn * 4);
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // the uploads read host vectors that die with this call
+    const size_t o_hits = place(Qn * k * sizeof(Hit));
+    const size_t o_nhits = place(Qn * 4);
+    const size_t o_found = place(Qn * 8);
+    char* base = nullptr;
+    chk(batch_alloc(b, (void**)&base, off));
+    if (e == hipSuccess) {
+        b->d_items = (decltype(b->d_items))(base + o_items);
+        b->d_witems = (decltype(b->d_witems))(base + o_witems);
+        b->d_terms = (decltype(b->d_terms))(base + o_terms);
+        b->d_groups = (decltype(b->d_groups))(base + o_groups);
+        b->d_queries = (decltype(b->d_queries))(base + o_queries);
+        b->d_segs = (decltype(b->d_segs))(base + o_segs);
+        b->d_wide_q = (uint32_t*)(base + o_wideq);
+        b->d_bounds = (uint32_t*)(base + o_bounds);
+        if (!direct) {
+            b->d_part_hits = (Hit*)(base + o_phits);
+            b->d_part_nhits = (uint32_t*)(base + o_pnhits);
+            b->d_part_found = (uint64_t*)(base + o_pfound);
+            b->d_heads = (uint32_t*)(base + o_heads);
+        }
+        b->d_hits = (Hit*)(base + o_hits);
+        b->d_nhits = (uint32_t*)(base + o_nhits);
+        b->d_found = (uint64_t*)(base + o_found);
+        b->out_span = o_found + Qn * 8 - o_hits;
+        b->off_nhits = o_nhits - o_hits;
+        b->off_found = o_found - o_hits;
+    }
+    if (e == hipSuccess && ctx->up_busy) {   // the previous batch's upload may still be reading the staging buffer
+        chk(hipEventSynchronize(ctx->up_done));
+        ctx->up_busy = false;
+    }
+    if (e == hipSuccess && up_bytes <= kStageMaxBytes && ctx->h_up_cap < up_bytes) {
+        if (ctx->h_up) (void)hipHostFree(ctx->h_up);
+        ctx->h_up = nullptr; ctx->h_up_cap = 0;
+        const size_t cap = std::max<size_t>(up_bytes + up_bytes / 2, 1 << 16);
+        if (hipHostMalloc(&ctx->h_up, cap, hipHostMallocDefault) == hipSuccess) ctx->h_up_cap = cap;
+        else { ctx->h_up = nullptr; (void)hipGetLastError(); }
+        if (!ctx->up_done) chk(hipEventCreateWithFlags(&ctx->up_done, hipEventDisableTiming));
+    }
+    if (e == hipSuccess) {
+        const bool staged = ctx->h_up_cap >= up_bytes && ctx->up_done;
+        char* hb = staged ? (char*)ctx->h_up : nullptr;
+        auto put = [&](size_t o, const void* src, size_t bytes) {
+            if (!bytes) return;
+            if (staged) std::memcpy(hb + o, src, bytes);
+            else chk(hipMemcpyAsync(base + o, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        };
+        put(o_items, sorted_items.data(), sorted_items.size() * sizeof(sorted_items[0]));
+        put(o_witems, sorted_witems.data(), sorted_witems.size() * sizeof(sorted_witems[0]));
+        put(o_terms, dterms.data(), dterms.size() * sizeof(dterms[0]));
+        put(o_groups, bgroups.data(), bgroups.size() * sizeof(bgroups[0]));
+        put(o_queries, dq.data(), dq.size() * sizeof(dq[0]));
+        put(o_segs, segs.data(), segs.size() * sizeof(segs[0]));
+        put(o_wideq, wide_q.data(), wide_q.size() * 4);
+        if (staged) {
+            chk(hipMemcpyAsync(base, hb, up_bytes, hipMemcpyHostToDevice, ctx->stream));
+            chk(hipEventRecord(ctx->up_done, ctx->stream));
+            if (e == hipSuccess) ctx->up_busy = true;
+        } else {
+            chk(hipStreamSynchronize(ctx->stream));   // the copies read host vectors that die with this call
+        }
+    }
     if (e != hipSuccess) {
         int rc = fail(ctx, e == hipErrorOutOfMemory ? NS_E_NOMEM : NS_E_HIP, "ns_batch_prepare: %s", hipGetErrorString(e));
         ns_batch_destroy(b);
@@ -760,8 +835,11 @@ extern "C" int ns_batch_run(ns_batch* b, int timed) {
         else launch_score<512, 12, 4>(and_mode, b->n_items, st, b->d_items, b->d_terms, b->d_segs, b->d_bounds, sh, sn, sf, b->K);
     }
     if (timed) HIPCHK(ctx, hipEventRecord(ev[2], st));
-    if (!b->direct && b->Q)
+    if (!b->direct && b->Q > b->n_wide_q)
         hipLaunchKernelGGL(k_merge, dim3((b->Q + 3) / 4), dim3(256), 0, st, b->d_queries, b->Q, b->d_part_hits, b->d_part_nhits,
+                           b->d_part_found, b->o_hits, b->o_nhits, b->o_found, b->K, b->d_heads);
+    if (!b->direct && b->n_wide_q)
+        hipLaunchKernelGGL(k_merge_wide, dim3(b->n_wide_q), dim3(256), 0, st, b->d_queries, b->d_wide_q, b->d_part_hits, b->d_part_nhits,
                            b->d_part_found, b->o_hits, b->o_nhits, b->o_found, b->K, b->d_heads);
     if (timed) HIPCHK(ctx, hipEventRecord(ev[3], st));
     HIPCHK(ctx, hipGetLastError());
@@ -791,6 +869,26 @@ extern "C" int ns_batch_fetch(ns_batch* b, ns_hit* hits_out, uint32_t* nhits_out
     if (!b->ran) return fail(ctx, NS_E_STATE, "ns_batch_fetch before ns_batch_run");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    const bool own_outputs = b->o_hits == b->d_hits && b->o_nhits == b->d_nhits && b->o_found == b->d_found;
+    if (b->Q && own_outputs && b->out_span <= kStageMaxBytes) {
+        if (ctx->h_down_cap < b->out_span) {
+            if (ctx->h_down) (void)hipHostFree(ctx->h_down);
+            ctx->h_down = nullptr; ctx->h_down_cap = 0;
+            const size_t cap = std::max<size_t>(b->out_span + b->out_span / 2, 1 << 16);
+            if (hipHostMalloc(&ctx->h_down, cap, hipHostMallocDefault) == hipSuccess) ctx->h_down_cap = cap;
+            else { ctx->h_down = nullptr; (void)hipGetLastError(); }
+        }
+        if (ctx->h_down_cap >= b->out_span) {
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_down, b->d_hits, b->out_span, hipMemcpyDeviceToHost, st));
+            int rc = ns_batch_sync(b);
+            if (rc != NS_OK) return rc;
+            const char* h = (const char*)ctx->h_down;
+            if (hits_out) std::memcpy(hits_out, h, (size_t)b->Q * b->K * sizeof(Hit));
+            if (nhits_out) std::memcpy(nhits_out, h + b->off_nhits, (size_t)b->Q * 4);
+            if (found_out) std::memcpy(found_out, h + b->off_found, (size_t)b->Q * 8);
+            return NS_OK;
+        }
+    }
     if (b->Q) {
         if (hits_out) HIPCHK(ctx, hipMemcpyAsync(hits_out, b->o_hits, (size_t)b->Q * b->K * sizeof(Hit), hipMemcpyDeviceToHost, st));
         if (nhits_out) HIPCHK(ctx, hipMemcpyAsync(nhits_out, b->o_nhits, (size_t)b->Q * 4, hipMemcpyDeviceToHost, st));

@@ -398,27 +398,23 @@ __global__ void __launch_bounds__(NT) k_score(const DevItem* __restrict__ items,
 }
 
 // ------------------------------------------------------------------------------------------------
-// One wave per query: tournament over the sorted partial lists of its work items.
-// Canonical order: score desc, seg asc, doc asc (the reference leaves ties unspecified).
-__global__ void __launch_bounds__(256) k_merge(const DevQuery* __restrict__ queries, uint32_t n_queries,
-                                               const Hit* __restrict__ part_hits, const uint32_t* __restrict__ part_nhits,
-                                               const uint64_t* __restrict__ part_found, Hit* __restrict__ out_hits,
-                                               uint32_t* __restrict__ out_nhits, uint64_t* __restrict__ out_found,
-                                               uint32_t K, uint32_t* __restrict__ heads /* one u32 per partial row */) {
-    const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (q >= n_queries) return;
-    const DevQuery dq = queries[q];
-    const uint32_t pb = dq.part_begin, pc = dq.part_count;
+// Joining the partial rows of one query.  Canonical order: score desc, seg asc, doc asc (the reference
+// leaves ties unspecified).
+//
+// merge_rows_wave: one wave, K rounds of "every lane proposes the best head among its rows, the wave
+// picks the winner" — O(K * rows / 64) row visits, right for the few rows a query of a large batch has.
+// k_merge_wide: one workgroup per query, for queries cut into MANY rows (a lone query is spread over
+// the whole chip: thousands of rows).  Rows are sorted, so the answer lies in the rows' prefixes with
+// score >= theta, where theta is (a lower bound of) the K-th largest row HEAD: two 11-bit histogram
+// passes over the heads find it, the prefixes are gathered into LDS, sorted once, and the first K
+// leave.  Cost is independent of K and linear in rows / 256.
+__host__ __device__ inline bool merge_is_wide(uint32_t part_count, uint32_t K) { return part_count > 64 && part_count >= K; }
 
-    uint64_t found = 0;
-    for (uint32_t i = lane; i < pc; i += 64) {
-        found += part_found[pb + i];
-        heads[pb + i] = 0;
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) found += __shfl_xor(found, d, 64);
-
+__device__ __forceinline__ void merge_rows_wave(uint32_t q, uint32_t pb, uint32_t pc, const Hit* __restrict__ part_hits,
+                                                const uint32_t* __restrict__ part_nhits, Hit* __restrict__ out_hits,
+                                                uint32_t* __restrict__ out_nhits, uint64_t* __restrict__ out_found, uint64_t found,
+                                                uint32_t K, uint32_t* __restrict__ heads, int lane) {
+    for (uint32_t i = lane; i < pc; i += 64) heads[pb + i] = 0;
     Hit* oh = out_hits + (uint64_t)q * K;
     uint32_t produced = 0;
     for (; produced < K; produced++) {
@@ -471,6 +467,152 @@ __global__ void __launch_bounds__(256) k_merge(const DevQuery* __restrict__ quer
         oh[i] = h;
     }
     if (lane == 0) {
+        out_nhits[q] = produced;
+        out_found[q] = found;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_merge(const DevQuery* __restrict__ queries, uint32_t n_queries,
+                                               const Hit* __restrict__ part_hits, const uint32_t* __restrict__ part_nhits,
+                                               const uint64_t* __restrict__ part_found, Hit* __restrict__ out_hits,
+                                               uint32_t* __restrict__ out_nhits, uint64_t* __restrict__ out_found,
+                                               uint32_t K, uint32_t* __restrict__ heads /* one u32 per partial row */) {
+    const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (q >= n_queries) return;
+    const DevQuery dq = queries[q];
+    const uint32_t pb = dq.part_begin, pc = dq.part_count;
+    if (merge_is_wide(pc, K)) return;   // k_merge_wide's
+    uint64_t found = 0;
+    for (uint32_t i = lane; i < pc; i += 64) found += part_found[pb + i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) found += __shfl_xor(found, d, 64);
+    merge_rows_wave(q, pb, pc, part_hits, part_nhits, out_hits, out_nhits, out_found, found, K, heads, lane);
+}
+
+constexpr uint32_t kMergeCap = 2048;    // candidates held in LDS; more than that (mass ties) falls back to the tournament
+constexpr uint32_t kMergeBins = 2048;   // 11 bits per histogram pass
+
+// K-th largest over the histogram: s_sel[0] = bin holding it (0xFFFFFFFF: fewer than `target` entries), s_sel[1] =
+// its rank inside that bin.  All 256 threads call; ends with a barrier.
+__device__ __forceinline__ void merge_select_bin(uint32_t* s_hist, uint32_t* s_part, uint32_t* s_sel, uint32_t target, uint32_t tid) {
+    uint32_t own = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kMergeBins / 256; j++) own += s_hist[tid * (kMergeBins / 256) + j];
+    s_part[tid] = own;
+    if (tid == 0) s_sel[0] = 0xFFFFFFFFu;
+    __syncthreads();
+    uint32_t above = 0;
+    for (uint32_t u = tid + 1; u < 256; u++) above += s_part[u];
+    if (above < target && above + own >= target) {
+        uint32_t acc = above;
+        for (int j = (int)(kMergeBins / 256) - 1; j >= 0; j--) {
+            const uint32_t c = s_hist[tid * (kMergeBins / 256) + j];
+            if (acc + c >= target) { s_sel[0] = tid * (kMergeBins / 256) + (uint32_t)j; s_sel[1] = target - acc; break; }
+            acc += c;
+        }
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) k_merge_wide(const DevQuery* __restrict__ queries, const uint32_t* __restrict__ wide_q,
+                                                    const Hit* __restrict__ part_hits, const uint32_t* __restrict__ part_nhits,
+                                                    const uint64_t* __restrict__ part_found, Hit* __restrict__ out_hits,
+                                                    uint32_t* __restrict__ out_nhits, uint64_t* __restrict__ out_found,
+                                                    uint32_t K, uint32_t* __restrict__ heads) {
+    __shared__ uint32_t s_hist[kMergeBins];
+    __shared__ uint32_t s_part[256];
+    __shared__ uint32_t s_sel[2];
+    __shared__ uint32_t s_ncand;
+    __shared__ uint64_t s_fsum[4];
+    __shared__ uint32_t s_cs[kMergeCap];
+    __shared__ uint64_t s_cid[kMergeCap];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t q = wide_q[blockIdx.x];
+    const DevQuery dq = queries[q];
+    const uint32_t pb = dq.part_begin, pc = dq.part_count;
+
+    uint64_t found = 0;
+    for (uint32_t i = tid; i < pc; i += 256) found += part_found[pb + i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) found += __shfl_xor(found, d, 64);
+    if ((tid & 63) == 0) s_fsum[tid >> 6] = found;
+    if (tid == 0) s_ncand = 0;
+
+    // theta: lower edge of the 22-bit bucket that holds the K-th largest row head
+    for (uint32_t i = tid; i < kMergeBins; i += 256) s_hist[i] = 0;
+    __syncthreads();
+    found = s_fsum[0] + s_fsum[1] + s_fsum[2] + s_fsum[3];
+    for (uint32_t i = tid; i < pc; i += 256)
+        if (part_nhits[pb + i]) atomicAdd(&s_hist[order_bits(part_hits[(uint64_t)(pb + i) * K].score) >> 21], 1u);
+    __syncthreads();
+    merge_select_bin(s_hist, s_part, s_sel, K, tid);
+    const uint32_t b1 = s_sel[0], k2 = s_sel[1];
+    uint32_t theta = 0;   // fewer than K rows hold anything: every entry is a candidate
+    if (b1 != 0xFFFFFFFFu) {
+        for (uint32_t i = tid; i < kMergeBins; i += 256) s_hist[i] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < pc; i += 256)
+            if (part_nhits[pb + i]) {
+                const uint32_t s = order_bits(part_hits[(uint64_t)(pb + i) * K].score);
+                if ((s >> 21) == b1) atomicAdd(&s_hist[(s >> 10) & (kMergeBins - 1)], 1u);
+            }
+        __syncthreads();
+        merge_select_bin(s_hist, s_part, s_sel, k2, tid);
+        theta = (b1 << 21) | (s_sel[0] << 10);
+    }
+
+    // gather every row's prefix with score >= theta
+    for (uint32_t i = tid; i < pc; i += 256) {
+        const uint32_t n = part_nhits[pb + i];
+        const Hit* row = part_hits + (uint64_t)(pb + i) * K;
+        for (uint32_t j = 0; j < n; j++) {
+            const Hit e = row[j];
+            const uint32_t s = order_bits(e.score);
+            if (s < theta) break;
+            const uint32_t slot = atomicAdd(&s_ncand, 1u);
+            if (slot < kMergeCap) { s_cs[slot] = s; s_cid[slot] = ((uint64_t)e.seg << 32) | e.doc; }
+        }
+    }
+    __syncthreads();
+    const uint32_t C = s_ncand;
+    if (C > kMergeCap) {   // uniform: one wave redoes the query the slow way
+        if (tid < 64) merge_rows_wave(q, pb, pc, part_hits, part_nhits, out_hits, out_nhits, out_found, found, K, heads, (int)tid);
+        return;
+    }
+    uint32_t P = 64;
+    while (P < C) P <<= 1;
+    for (uint32_t i = C + tid; i < P; i += 256) { s_cs[i] = 0; s_cid[i] = ~0ull; }
+    __syncthreads();
+    // bitonic sort, best first: (score bits desc, id asc)
+    for (uint32_t k = 2; k <= P; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < (P >> 1); t += 256) {
+                const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                const uint32_t sa = s_cs[lo], sb = s_cs[hi];
+                const uint64_t ia = s_cid[lo], ib = s_cid[hi];
+                const bool b_better = sb > sa || (sb == sa && ib < ia);
+                const bool desc = (lo & k) == 0;   // this run wants best first
+                if (b_better == desc) { s_cs[lo] = sb; s_cs[hi] = sa; s_cid[lo] = ib; s_cid[hi] = ia; }
+            }
+            __syncthreads();
+        }
+    const uint32_t produced = C < K ? C : K;
+    Hit* oh = out_hits + (uint64_t)q * K;
+    for (uint32_t i = tid; i < K; i += 256) {
+        Hit h;
+        if (i < produced) {
+            h.score = unorder_bits(s_cs[i]);
+            h.seg = (uint32_t)(s_cid[i] >> 32);
+            h.doc = (uint32_t)s_cid[i];
+        } else {
+            h.score = -__builtin_inff();
+            h.seg = 0xFFFFFFFFu;
+            h.doc = 0xFFFFFFFFu;
+        }
+        oh[i] = h;
+    }
+    if (tid == 0) {
         out_nhits[q] = produced;
         out_found[q] = found;
     }

@@ -306,6 +306,46 @@ def test_sparse_lists_over_20m_docs_span_clamp():
     L.ns_ctx_destroy(ctx)
 
 
+def test_lone_query_wide_merge_ties_and_thresholds():
+    """A lone query is cut into thousands of doc ranges and joined by k_merge_wide (threshold from the
+    row heads, one sort).  Three shapes through the raw C-ABI against the numpy restatement: every
+    score equal (mass ties: more candidates than the LDS buffer holds -> tournament fall-back), two
+    score levels (ties AT the threshold), and distinct scores."""
+    L = nsbind.hip_lib()
+    ctx = C.c_void_p()
+    assert L.ns_ctx_create(0, C.byref(ctx)) == 0
+    N = 600_000
+    rng = np.random.default_rng(3)
+    docs = np.arange(0, N, 2, dtype=np.uint32)
+    shapes = {
+        "all_equal": (np.full(N, 100, dtype=np.uint32), np.ones(len(docs), dtype=np.uint32)),
+        "two_levels": (np.full(N, 100, dtype=np.uint32), np.where(np.arange(len(docs)) % 9973 == 5, 2, 1).astype(np.uint32)),
+        "distinct": (rng.integers(20, 5000, size=N, dtype=np.uint32), rng.integers(1, 9, size=len(docs), dtype=np.uint32)),
+    }
+    for name, (doc_len, tfs) in shapes.items():
+        avgdl = float(np.float32(doc_len.astype(np.float64).mean()))
+        flat = np.stack([docs, tfs], axis=1).astype(np.uint32).ravel()
+        seg = C.c_void_p()
+        assert L.ns_segment_upload(ctx, 0, N, C.c_float(avgdl), doc_len.ctypes.data, flat.ctypes.data, flat.nbytes, C.byref(seg)) == 0, L.ns_last_error(ctx)
+        qd = np.zeros(1, dtype=nsbind.QDESC_DTYPE)
+        qd[0] = (0, 1)
+        refs = np.array([(0, len(docs), 0, 1.75, 1.0)], dtype=nsbind.TERM_DTYPE)
+        acc = _np_bm25([(docs, tfs)], [0], [1.75], [1.0], doc_len, avgdl)
+        full = sorted(acc.items(), key=lambda kv: (-float(kv[1]), kv[0]))[:100]
+        for min_items in (0, 20000):
+            assert L.ns_set_tuning(ctx, 0, min_items, 0) == 0
+            for k in (1, 10, 64, 100):
+                rc, hits, nhits, found = nsbind.search_batch_raw(ctx, qd, refs, k)
+                assert rc == 0, L.ns_last_error(ctx)
+                order = full[:k]
+                assert int(found[0]) == len(acc) and int(nhits[0]) == len(order), (name, k)
+                assert [int(d) for d in hits[0, :len(order)]["doc"]] == [d for d, _ in order], (name, k, min_items)
+                np.testing.assert_array_equal(hits[0, :len(order)]["score"].view(np.uint32), np.array([v for _, v in order], dtype=np.float32).view(np.uint32))
+        assert L.ns_set_tuning(ctx, 0, 0, 0) == 0
+        assert L.ns_segment_release(ctx, seg) == 0
+    L.ns_ctx_destroy(ctx)
+
+
 def test_many_terms_per_query(engines):
     """More scored terms than one wave-pass handles (64) and than the reference's expansion cap (40)."""
     g, eng, ora = engines("mid1")
@@ -363,6 +403,10 @@ def test_full_size_1m_docs_properties_and_sample(index_factory):
             idx = np.linspace(0, Q - 1, nsample).astype(int)
             sub = [queries[i] for i in idx]
             assert_same((hits[idx], nhits[idx], found[idx], usable[idx]), ora.search_batch(sub, K, flags, threads=16), sub, cfg + " full")
+            # the same queries one at a time (each spread over the whole chip, joined by k_merge_wide)
+            for i in idx[:12]:
+                lone = eng.search_batch([queries[i]], K, flags)
+                assert_same(lone, (hits[i:i + 1], nhits[i:i + 1], found[i:i + 1], usable[i:i + 1]), [queries[i]], cfg + " lone")
     finally:
         eng.close()
         ora.close()

@@ -32,6 +32,16 @@ for q in qs[:500]:
     eng.search_json(q, 10)
 t1 = time.perf_counter()
 print(f"one query at a time, Engine::search(query, 10) -> decorated JSON text: {1e6 * (t1 - t0) / 500:.0f} us per query (mean of 500)")
+acc = [0.0] * 5
+for q in qs[:500]:
+    t0 = time.perf_counter(); qd, refs, usable = eng.build_refs([q]); t1 = time.perf_counter()
+    b = eng.prepare([q], 10); t2 = time.perf_counter()
+    b.run(False); b.sync(); t3 = time.perf_counter()
+    b.fetch(); t4 = time.perf_counter(); b.close(); t5 = time.perf_counter()
+    for i, d in enumerate((t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
+        acc[i] += d
+print("one query at a time, by stage (us, mean of 500, ctypes call overhead included): query prep %.0f | prepare (incl. query prep) %.0f | "
+      "run+sync %.0f | fetch %.0f | destroy %.0f" % tuple(1e6 * a / 500 for a in acc))
 eng.search_batch_json(qs[:64], 10)
 for rep in range(3):
     t0 = time.perf_counter(); raw, offs = eng.search_batch_json(qs, 10, decode=False); t1 = time.perf_counter()
