@@ -60,6 +60,9 @@ struct ns_ctx {
     bool up_busy = false;
     void* h_down = nullptr;
     size_t h_down_cap = 0;
+    // A small batch has its result arrays IN h_down (pinned host memory is device-addressable): the kernels
+    // write the few hits over PCIe themselves and fetch is a stream sync + memcpy.  One batch at a time owns it.
+    struct ns_batch* down_owner = nullptr;
 };
 
 static thread_local std::string g_create_err;
@@ -379,6 +382,8 @@ struct ns_batch {
 
 static constexpr size_t kPoolMaxBytes = 1ull << 30;   // cached blocks beyond this are released
 static constexpr size_t kStageMaxBytes = 256ull << 20;   // larger batches upload/fetch array by array
+static constexpr size_t kPullUploadBytes = 256 << 10;     // uploads up to this size are pulled by a kernel instead of the DMA engine
+static constexpr size_t kHostResultBytes = 64 << 10;      // result arrays up to this size live in pinned host memory
 
 static hipError_t pool_alloc(ns_ctx* ctx, void** out, size_t n) {
     n = (std::max<size_t>(n, 1) + 255) & ~(size_t)255;
@@ -409,10 +414,16 @@ static void pool_free(ns_ctx* ctx, void* p, size_t n) {
     ctx->pool_bytes += n;
 }
 
+__global__ void __launch_bounds__(256) k_pull(uint4* __restrict__ dst, const uint4* __restrict__ src, uint32_t n16) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+
 extern "C" void ns_batch_destroy(ns_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
+    if (b->ctx->down_owner == b) b->ctx->down_owner = nullptr;
     for (auto& blk : b->blocks) pool_free(b->ctx, blk.first, blk.second);   // the stream is idle: safe to hand on
     for (auto& e : b->ev_pool) if (e) (void)hipEventDestroy(e);
     delete b;
@@ -700,6 +711,20 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
         b->out_span = o_found + Qn * 8 - o_hits;
         b->off_nhits = o_nhits - o_hits;
         b->off_found = o_found - o_hits;
+        if (b->out_span <= kHostResultBytes && !ctx->down_owner) {
+            if (ctx->h_down_cap < b->out_span) {
+                if (ctx->h_down) (void)hipHostFree(ctx->h_down);
+                ctx->h_down = nullptr; ctx->h_down_cap = 0;
+                if (hipHostMalloc(&ctx->h_down, kHostResultBytes, hipHostMallocDefault) == hipSuccess) ctx->h_down_cap = kHostResultBytes;
+                else { ctx->h_down = nullptr; (void)hipGetLastError(); }
+            }
+            if (ctx->h_down_cap >= b->out_span) {
+                ctx->down_owner = b;
+                b->d_hits = (Hit*)ctx->h_down;
+                b->d_nhits = (uint32_t*)((char*)ctx->h_down + b->off_nhits);
+                b->d_found = (uint64_t*)((char*)ctx->h_down + b->off_found);
+            }
+        }
     }
     if (e == hipSuccess && ctx->up_busy) {   // the previous batch's upload may still be reading the staging buffer
         chk(hipEventSynchronize(ctx->up_done));
@@ -729,7 +754,13 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
         put(o_segs, segs.data(), segs.size() * sizeof(segs[0]));
         put(o_wideq, wide_q.data(), wide_q.size() * 4);
         if (staged) {
-            chk(hipMemcpyAsync(base, hb, up_bytes, hipMemcpyHostToDevice, ctx->stream));
+            // a small upload is pulled by a kernel (the pinned buffer is device-addressable): a DMA-engine copy
+            // followed by a kernel costs ~11 us of cross-engine hand-over, more than the copy itself
+            if (up_bytes <= kPullUploadBytes)
+                hipLaunchKernelGGL(k_pull, dim3((uint32_t)((up_bytes / 16 + 255) / 256)), dim3(256), 0, ctx->stream,
+                                   (uint4*)base, (const uint4*)hb, (uint32_t)(up_bytes / 16));
+            else
+                chk(hipMemcpyAsync(base, hb, up_bytes, hipMemcpyHostToDevice, ctx->stream));
             chk(hipEventRecord(ctx->up_done, ctx->stream));
             if (e == hipSuccess) ctx->up_busy = true;
         } else {
@@ -870,7 +901,16 @@ extern "C" int ns_batch_fetch(ns_batch* b, ns_hit* hits_out, uint32_t* nhits_out
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const bool own_outputs = b->o_hits == b->d_hits && b->o_nhits == b->d_nhits && b->o_found == b->d_found;
-    if (b->Q && own_outputs && b->out_span <= kStageMaxBytes) {
+    if (b->Q && own_outputs && ctx->down_owner == b) {   // the results are already in host memory
+        int rc = ns_batch_sync(b);
+        if (rc != NS_OK) return rc;
+        const char* h = (const char*)ctx->h_down;
+        if (hits_out) std::memcpy(hits_out, h, (size_t)b->Q * b->K * sizeof(Hit));
+        if (nhits_out) std::memcpy(nhits_out, h + b->off_nhits, (size_t)b->Q * 4);
+        if (found_out) std::memcpy(found_out, h + b->off_found, (size_t)b->Q * 8);
+        return NS_OK;
+    }
+    if (b->Q && own_outputs && !ctx->down_owner && b->out_span <= kStageMaxBytes) {
         if (ctx->h_down_cap < b->out_span) {
             if (ctx->h_down) (void)hipHostFree(ctx->h_down);
             ctx->h_down = nullptr; ctx->h_down_cap = 0;

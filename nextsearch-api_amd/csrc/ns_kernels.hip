@@ -492,6 +492,7 @@ __global__ void __launch_bounds__(256) k_merge(const DevQuery* __restrict__ quer
 
 constexpr uint32_t kMergeCap = 2048;    // candidates held in LDS; more than that (mass ties) falls back to the tournament
 constexpr uint32_t kMergeBins = 2048;   // 11 bits per histogram pass
+constexpr uint32_t kMergeRegRows = 32;  // row heads cached per thread (a lone query has at most n_cus * 24 + a few rows)
 
 // K-th largest over the histogram: s_sel[0] = bin holding it (0xFFFFFFFF: fewer than `target` entries), s_sel[1] =
 // its rank inside that bin.  All 256 threads call; ends with a barrier.
@@ -532,8 +533,21 @@ __global__ void __launch_bounds__(256) k_merge_wide(const DevQuery* __restrict__
     const DevQuery dq = queries[q];
     const uint32_t pb = dq.part_begin, pc = dq.part_count;
 
+    // row heads are read once: order_bits(head score) of this thread's first kMergeRegRows rows stay in registers
+    // (0 == empty row); rows beyond that (a query cut into > 256 * kMergeRegRows ranges) are re-read.
+    constexpr uint32_t R = kMergeRegRows;
+    uint32_t hs[R];
     uint64_t found = 0;
-    for (uint32_t i = tid; i < pc; i += 256) found += part_found[pb + i];
+#pragma unroll
+    for (uint32_t r = 0; r < R; r++) {
+        const uint32_t i = tid + r * 256;
+        hs[r] = 0;
+        if (i < pc) {
+            found += part_found[pb + i];
+            if (part_nhits[pb + i]) hs[r] = order_bits(part_hits[(uint64_t)(pb + i) * K].score);
+        }
+    }
+    for (uint32_t i = tid + R * 256; i < pc; i += 256) found += part_found[pb + i];
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) found += __shfl_xor(found, d, 64);
     if ((tid & 63) == 0) s_fsum[tid >> 6] = found;
@@ -543,7 +557,10 @@ __global__ void __launch_bounds__(256) k_merge_wide(const DevQuery* __restrict__
     for (uint32_t i = tid; i < kMergeBins; i += 256) s_hist[i] = 0;
     __syncthreads();
     found = s_fsum[0] + s_fsum[1] + s_fsum[2] + s_fsum[3];
-    for (uint32_t i = tid; i < pc; i += 256)
+#pragma unroll
+    for (uint32_t r = 0; r < R; r++)
+        if (hs[r]) atomicAdd(&s_hist[hs[r] >> 21], 1u);
+    for (uint32_t i = tid + R * 256; i < pc; i += 256)
         if (part_nhits[pb + i]) atomicAdd(&s_hist[order_bits(part_hits[(uint64_t)(pb + i) * K].score) >> 21], 1u);
     __syncthreads();
     merge_select_bin(s_hist, s_part, s_sel, K, tid);
@@ -552,7 +569,10 @@ __global__ void __launch_bounds__(256) k_merge_wide(const DevQuery* __restrict__
     if (b1 != 0xFFFFFFFFu) {
         for (uint32_t i = tid; i < kMergeBins; i += 256) s_hist[i] = 0;
         __syncthreads();
-        for (uint32_t i = tid; i < pc; i += 256)
+#pragma unroll
+        for (uint32_t r = 0; r < R; r++)
+            if (hs[r] && (hs[r] >> 21) == b1) atomicAdd(&s_hist[(hs[r] >> 10) & (kMergeBins - 1)], 1u);
+        for (uint32_t i = tid + R * 256; i < pc; i += 256)
             if (part_nhits[pb + i]) {
                 const uint32_t s = order_bits(part_hits[(uint64_t)(pb + i) * K].score);
                 if ((s >> 21) == b1) atomicAdd(&s_hist[(s >> 10) & (kMergeBins - 1)], 1u);
@@ -563,7 +583,7 @@ __global__ void __launch_bounds__(256) k_merge_wide(const DevQuery* __restrict__
     }
 
     // gather every row's prefix with score >= theta
-    for (uint32_t i = tid; i < pc; i += 256) {
+    auto gather_row = [&](uint32_t i) {
         const uint32_t n = part_nhits[pb + i];
         const Hit* row = part_hits + (uint64_t)(pb + i) * K;
         for (uint32_t j = 0; j < n; j++) {
@@ -573,7 +593,11 @@ __global__ void __launch_bounds__(256) k_merge_wide(const DevQuery* __restrict__
             const uint32_t slot = atomicAdd(&s_ncand, 1u);
             if (slot < kMergeCap) { s_cs[slot] = s; s_cid[slot] = ((uint64_t)e.seg << 32) | e.doc; }
         }
-    }
+    };
+#pragma unroll
+    for (uint32_t r = 0; r < R; r++)
+        if (hs[r] && hs[r] >= theta) gather_row(tid + r * 256);
+    for (uint32_t i = tid + R * 256; i < pc; i += 256) gather_row(i);
     __syncthreads();
     const uint32_t C = s_ncand;
     if (C > kMergeCap) {   // uniform: one wave redoes the query the slow way
