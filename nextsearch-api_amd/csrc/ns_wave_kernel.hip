@@ -162,12 +162,33 @@ __device__ __forceinline__ float ns_div_short(float a, float b) {
     t = __builtin_fmaf(-b, q, a);
     return __builtin_fmaf(t, r, q);
 }
+// Two divisions per lane in the packed fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32 are IEEE, full rate on gfx950:
+// the same seven roundings per division as ns_div_short, at half the VALU issue slots; only v_rcp_f32 stays scalar).
+typedef float ns_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ns_f2 ns_div_short2(ns_f2 a, ns_f2 b) {
+    ns_f2 r;
+    r.x = __builtin_amdgcn_rcpf(b.x);
+    r.y = __builtin_amdgcn_rcpf(b.y);
+    const ns_f2 one = {1.0f, 1.0f};
+    const ns_f2 e = __builtin_elementwise_fma(-b, r, one);
+    r = __builtin_elementwise_fma(e, r, r);
+    ns_f2 q = a * r;
+    ns_f2 t = __builtin_elementwise_fma(-b, q, a);
+    q = __builtin_elementwise_fma(t, r, q);
+    t = __builtin_elementwise_fma(-b, q, a);
+    return __builtin_elementwise_fma(t, r, q);
+}
 // q[j] = a[j] / b[j] for N independent lanes-wide divisions; `fast` is wave-uniform (one scalar branch)
 template <int N>
 __device__ __forceinline__ void ns_div_n(float (&q)[N], const float (&a)[N], const float (&b)[N], bool fast) {
     if (fast) {
 #pragma unroll
-        for (int j = 0; j < N; j++) q[j] = ns_div_short(a[j], b[j]);
+        for (int j = 0; j + 1 < N; j += 2) {
+            const ns_f2 a2 = {a[j], a[j + 1]}, b2 = {b[j], b[j + 1]};
+            const ns_f2 q2 = ns_div_short2(a2, b2);
+            q[j] = q2.x; q[j + 1] = q2.y;
+        }
+        if (N & 1) q[N - 1] = ns_div_short(a[N - 1], b[N - 1]);
     } else {
 #pragma unroll
         for (int j = 0; j < N; j++) q[j] = a[j] / b[j];
