@@ -39,6 +39,7 @@ extern "C" {
 /* flags for ns_search_batch / ns_batch_prepare */
 #define NS_FLAG_OR      0u   /* reference semantics: every touched doc is a candidate (src/api_engine.cpp:449-492) */
 #define NS_FLAG_AND     1u   /* extension (BASELINE config 2): keep docs matched by every term ref of their segment */
+#define NS_INFO_IMPACTS 0x100u /* ns_batch_info.flags only (output): the batch reads impact streams (ns_segment_build_impacts) */
 
 typedef struct ns_ctx   ns_ctx;
 typedef struct ns_seg   ns_seg;
@@ -106,6 +107,19 @@ const char* ns_device_name(ns_ctx* ctx);
 int ns_segment_upload(ns_ctx* ctx, uint32_t seg_id, uint32_t n_docs, float avgdl,
                       const uint32_t* doc_len, const void* postings, uint64_t nbytes, ns_seg** out);
 int ns_segment_release(ns_ctx* ctx, ns_seg* seg);
+
+/* Optional second posting stream of a segment (a format loaded NEXT TO the reference's).
+ * For every list given here the device stores {u32 docId, f32 term score} per posting, index-aligned with the
+ * uploaded {docId, tf} stream, where term score = (idf * (tf * (k1 + 1))) / (tf + k1*((1-b) + b*dl/avgdl)) —
+ * src/api_engine.cpp:477-479 evaluated ONCE per posting with the same fp32 operations, instead of once per
+ * posting per query.  A batch reads the impact stream when EVERY term ref in it names a registered list with
+ * the bit-identical idf (otherwise the whole batch takes the {docId, tf} path); results are bit-identical
+ * either way.  Costs 8 B of HBM per posting of the segment.  byte_off/counts as in ns_term_ref; lists must
+ * not overlap.  May be called again to add lists or to replace a list's idf. */
+int ns_segment_build_impacts(ns_ctx* ctx, ns_seg* seg, const uint64_t* byte_off, const uint32_t* counts,
+                             const float* idfs, uint32_t n_lists);
+/* on = 0: batches prepared from now on ignore impact streams (default: on = 1). */
+int ns_ctx_use_impacts(ns_ctx* ctx, int on);
 
 /* ---- one-shot search (host buffers in, host buffers out) ------------------------------------ */
 /* hits_out: Q*K entries, query-major, best first: score desc, then seg_id asc, then doc_id asc

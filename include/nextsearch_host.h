@@ -30,6 +30,11 @@ void nsh_engine_close(nsh_engine* e);
 const char* nsh_engine_error(nsh_engine* e);
 ns_ctx* nsh_engine_ctx(nsh_engine* e);
 
+/* Optional impact streams for every list of every loaded lexicon (include/nextsearch_hip.h:
+ * ns_segment_build_impacts / ns_ctx_use_impacts).  Not part of reload(): 8 B of HBM per posting. */
+int  nsh_engine_build_impacts(nsh_engine* e);
+void nsh_engine_use_impacts(nsh_engine* e, int on);
+
 uint32_t nsh_engine_num_segments(nsh_engine* e);
 const char* nsh_engine_segment_name(nsh_engine* e, uint32_t seg);
 int nsh_engine_segment_info(nsh_engine* e, uint32_t seg, uint32_t* n_docs, float* avgdl, uint64_t* n_postings,

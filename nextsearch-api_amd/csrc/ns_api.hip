@@ -34,6 +34,21 @@ struct ns_seg {
     float* d_norm = nullptr;    // per doc
     float* d_pnorm = nullptr;   // per posting
     bool norm_safe = false;     // every norm lies in [2^-20, 2^30]: the BM25 division may take its short form (ns_div_short)
+    // Optional impact stream (ns_segment_build_impacts): {docId, term score bits} per posting of the registered lists,
+    // index-aligned with d_postings.  `imp_tab`: open-addressed (first posting index -> count, idf bits) of those lists.
+    uint2* d_impacts = nullptr;
+    struct ImpList { uint32_t first = 0xFFFFFFFFu, count = 0, idf_bits = 0; };
+    std::vector<ImpList> imp_tab;   // size is a power of two (or 0)
+    size_t imp_lists = 0;
+    bool imp_has(uint32_t first, uint32_t count, uint32_t idf_bits) const {
+        if (imp_tab.empty()) return false;
+        const size_t mask = imp_tab.size() - 1;
+        for (size_t h = ((size_t)first * 0x9E3779B1u) & mask;; h = (h + 1) & mask) {
+            const ImpList& e = imp_tab[h];
+            if (e.first == first) return e.count == count && e.idf_bits == idf_bits;
+            if (e.first == 0xFFFFFFFFu) return false;
+        }
+    }
 };
 
 struct ns_ctx {
@@ -63,6 +78,7 @@ struct ns_ctx {
     // A small batch has its result arrays IN h_down (pinned host memory is device-addressable): the kernels
     // write the few hits over PCIe themselves and fetch is a stream sync + memcpy.  One batch at a time owns it.
     struct ns_batch* down_owner = nullptr;
+    bool use_impacts = true;   // batches take the impact stream when every list they touch has one (ns_ctx_use_impacts)
 };
 
 static thread_local std::string g_create_err;
@@ -201,6 +217,7 @@ extern "C" void ns_ctx_destroy(ns_ctx* ctx) {
         (void)hipFree(s->d_postings);
         (void)hipFree(s->d_norm);
         (void)hipFree(s->d_pnorm);
+        (void)hipFree(s->d_impacts);
         delete s;
     }
     for (auto& blk : ctx->pool) (void)hipFree(blk.p);
@@ -331,8 +348,103 @@ extern "C" int ns_segment_release(ns_ctx* ctx, ns_seg* seg) {
     (void)hipFree(seg->d_postings);
     (void)hipFree(seg->d_norm);
     (void)hipFree(seg->d_pnorm);
+    (void)hipFree(seg->d_impacts);
     ctx->segs[seg->id] = nullptr;
     delete seg;
+    return NS_OK;
+}
+
+// One thread per posting: the list that holds it is found by binary search over the (sorted) list starts.
+// The arithmetic is src/api_engine.cpp:477-479 operation for operation with the compiler's IEEE division —
+// the expression the scoring kernels evaluate per posting per query when no impact stream exists.
+__global__ void __launch_bounds__(256) k_build_impacts(const uint2* __restrict__ postings, const float* __restrict__ pnorm,
+                                                       uint2* __restrict__ impacts, const uint32_t* __restrict__ starts,
+                                                       const uint32_t* __restrict__ counts, const float* __restrict__ idfs,
+                                                       uint32_t n_lists, uint64_t n_postings) {
+    for (uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x; p < n_postings; p += (uint64_t)gridDim.x * 256) {
+        uint32_t lo = 0, hi = n_lists;
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if ((uint64_t)starts[mid] <= p) lo = mid + 1; else hi = mid;
+        }
+        if (lo == 0) continue;
+        const uint32_t l = lo - 1;
+        if (p - starts[l] >= counts[l]) continue;
+        const uint2 pv = postings[p];
+        const float tf = (float)pv.y;
+        const float den = tf + pnorm[p];
+        const float num = idfs[l] * (tf * (1.2f + 1.0f));
+        impacts[p] = make_uint2(pv.x, __float_as_uint(num / den));
+    }
+}
+
+extern "C" int ns_segment_build_impacts(ns_ctx* ctx, ns_seg* seg, const uint64_t* byte_off, const uint32_t* counts,
+                                        const float* idfs, uint32_t n_lists) {
+    if (!ctx || !seg) return fail(ctx, NS_E_INVAL, "ns_segment_build_impacts: null argument");
+    if (seg->id >= ctx->segs.size() || ctx->segs[seg->id] != seg) return fail(ctx, NS_E_INVAL, "segment does not belong to this ctx");
+    if (n_lists && (!byte_off || !counts || !idfs)) return fail(ctx, NS_E_INVAL, "null list arrays");
+    if (!n_lists || !seg->n_postings) return NS_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    struct L { uint32_t first, count; float idf; };
+    std::vector<L> lists;
+    lists.reserve(n_lists);
+    for (uint32_t i = 0; i < n_lists; i++) {
+        if (byte_off[i] % 8 != 0) return fail(ctx, NS_E_INVAL, "list %u: byte offset %llu is not a multiple of 8", i, (unsigned long long)byte_off[i]);
+        const uint64_t first = byte_off[i] / 8;
+        if (first + counts[i] > seg->n_postings) return fail(ctx, NS_E_INVAL, "list %u runs past the segment's postings", i);
+        if (counts[i]) lists.push_back({(uint32_t)first, counts[i], idfs[i]});
+    }
+    std::sort(lists.begin(), lists.end(), [](const L& a, const L& b) { return a.first < b.first; });
+    for (size_t i = 1; i < lists.size(); i++)
+        if (lists[i - 1].first + (uint64_t)lists[i - 1].count > lists[i].first) return fail(ctx, NS_E_INVAL, "lists overlap at posting %u", lists[i].first);
+    if (lists.empty()) return NS_OK;
+    const size_t kPadPostings = 256;
+    hipError_t e = hipSuccess;
+    if (!seg->d_impacts) {
+        e = hipMalloc((void**)&seg->d_impacts, (seg->n_postings + kPadPostings) * 8);
+        if (e != hipSuccess) { seg->d_impacts = nullptr; return fail(ctx, NS_E_NOMEM, "hipMalloc impact stream (%llu B): %s", (unsigned long long)(seg->n_postings * 8), hipGetErrorString(e)); }
+        e = hipMemsetAsync(seg->d_impacts, 0xFF, (seg->n_postings + kPadPostings) * 8, ctx->stream);   // docId ~0: never taken
+    }
+    const size_t n = lists.size();
+    std::vector<uint32_t> h_starts(n), h_counts(n);
+    std::vector<float> h_idfs(n);
+    for (size_t i = 0; i < n; i++) { h_starts[i] = lists[i].first; h_counts[i] = lists[i].count; h_idfs[i] = lists[i].idf; }
+    uint32_t* d_tmp = nullptr;
+    if (e == hipSuccess) e = hipMalloc((void**)&d_tmp, n * 12);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_tmp, h_starts.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_tmp + n, h_counts.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_tmp + 2 * n, h_idfs.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((seg->n_postings + 255) / 256, 1u << 16);
+        hipLaunchKernelGGL(k_build_impacts, dim3(blocks), dim3(256), 0, ctx->stream, seg->d_postings, seg->d_pnorm, seg->d_impacts,
+                           d_tmp, d_tmp + n, (const float*)(d_tmp + 2 * n), (uint32_t)n, seg->n_postings);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_tmp);
+    if (e != hipSuccess) return fail(ctx, NS_E_HIP, "ns_segment_build_impacts: %s", hipGetErrorString(e));
+    // registry: old entries + new ones (a list given again replaces its entry)
+    std::vector<ns_seg::ImpList> all;
+    for (const auto& t : seg->imp_tab) if (t.first != 0xFFFFFFFFu) all.push_back(t);
+    for (const auto& l : lists) { ns_seg::ImpList t; t.first = l.first; t.count = l.count; std::memcpy(&t.idf_bits, &l.idf, 4); all.push_back(t); }
+    size_t cap = 16;
+    while (cap < all.size() * 2) cap <<= 1;
+    std::vector<ns_seg::ImpList> tab(cap);
+    size_t distinct = 0;
+    for (const auto& t : all) {
+        for (size_t h = ((size_t)t.first * 0x9E3779B1u) & (cap - 1);; h = (h + 1) & (cap - 1)) {
+            if (tab[h].first == 0xFFFFFFFFu) { tab[h] = t; distinct++; break; }
+            if (tab[h].first == t.first) { tab[h] = t; break; }
+        }
+    }
+    seg->imp_tab.swap(tab);
+    seg->imp_lists = distinct;
+    return NS_OK;
+}
+
+extern "C" int ns_ctx_use_impacts(ns_ctx* ctx, int on) {
+    if (!ctx) return NS_E_INVAL;
+    ctx->use_impacts = on != 0;
     return NS_OK;
 }
 
@@ -348,6 +460,7 @@ struct ns_batch {
     uint32_t n_terms = 0, n_parts = 0;
     uint64_t postings = 0;
     bool direct = false;   // every query has exactly one work item: the scoring kernel writes final rows
+    bool imp = false;      // every list of the batch has an impact stream: the kernels read {docId, score} instead of {docId, tf} + norm
     // device
     DevItem* d_items = nullptr;
     DevWItem* d_witems = nullptr;
@@ -455,6 +568,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
         if (ns_seg* s = ctx->segs[i]) {
             d.postings = s->d_postings;
             d.pnorm = s->d_pnorm;
+            d.impacts = s->d_impacts;
             d.norm = s->d_norm;
             d.n_postings = s->n_postings;
             d.n_docs = s->n_docs;
@@ -469,6 +583,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
     std::vector<HostGroup> groups;
     std::vector<uint32_t> qgroup_begin(n_queries + 1, 0);
     uint64_t bounds_total = 0, postings_total = 0;
+    bool all_imp = ctx->use_impacts && ctx->variant == 0;   // stays true while every list met so far has an impact stream built with this idf
     std::vector<uint32_t> seg_ids;   // scratch
     for (uint32_t q = 0; q < n_queries; q++) {
         qgroup_begin[q] = (uint32_t)groups.size();
@@ -502,6 +617,10 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                 dterms.push_back(t);
                 hg.cost += r.count;
                 hg.cmax = std::max<uint64_t>(hg.cmax, r.count);
+                if (all_imp) {
+                    uint32_t ib; std::memcpy(&ib, &r.idf, 4);
+                    all_imp = ctx->segs[sid]->imp_has((uint32_t)(r.byte_off / 8), r.count, ib);
+                }
                 // 2^-30 <= idf <= 2^30 (and finite): see ns_div_short
                 if (!(r.idf >= 9.313225746154785e-10f && r.idf <= 1073741824.0f)) hg.fast_div = false;
             }
@@ -657,6 +776,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
     b->n_parts = direct ? 0 : n_rows;
     b->postings = postings_total;
     b->direct = direct;
+    b->imp = all_imp && postings_total > 0;
 
     // One device block per batch: [descriptors, uploaded in one copy][scratch][hits | nhits | found, fetched in one copy]
     hipError_t e = hipSuccess;
@@ -817,7 +937,10 @@ extern "C" int ns_batch_run(ns_batch* b, int timed) {
 #define NS_U(CBV, TM, N, PTR)                                                                                      \
         {                                                                                                          \
             dim3 g_(((N) + kUscoreWavesPerBlock - 1) / kUscoreWavesPerBlock);                                     \
-            if (and_mode) hipLaunchKernelGGL((k_uscore<512, 192, true, CBV, TM>), g_, block, 0, st, (PTR), (N), b->d_terms, b->d_segs, sh, sn, sf, b->K); \
+            if (b->imp) {                                                                                          \
+                if (and_mode) hipLaunchKernelGGL((k_uscore<512, 192, true, CBV, TM, true>), g_, block, 0, st, (PTR), (N), b->d_terms, b->d_segs, sh, sn, sf, b->K); \
+                else hipLaunchKernelGGL((k_uscore<512, 192, false, CBV, TM, true>), g_, block, 0, st, (PTR), (N), b->d_terms, b->d_segs, sh, sn, sf, b->K);         \
+            } else if (and_mode) hipLaunchKernelGGL((k_uscore<512, 192, true, CBV, TM>), g_, block, 0, st, (PTR), (N), b->d_terms, b->d_segs, sh, sn, sf, b->K); \
             else hipLaunchKernelGGL((k_uscore<512, 192, false, CBV, TM>), g_, block, 0, st, (PTR), (N), b->d_terms, b->d_segs, sh, sn, sf, b->K);         \
         }
         const uint32_t n_narrow = b->n_class[0], n_wide = b->n_witems - b->n_class[0];
@@ -946,7 +1069,7 @@ extern "C" int ns_batch_get_info(ns_batch* b, ns_batch_info* info) {
     info->n_term_refs = b->n_terms;
     info->tile_docs = b->tile_docs;
     info->k = b->K;
-    info->flags = b->flags;
+    info->flags = b->flags | (b->imp ? NS_INFO_IMPACTS : 0u);
     info->last_score_kernel_ms = b->last_score_ms;
     info->last_total_ms = b->last_total_ms;
     info->timed_runs = b->timed_runs;

@@ -31,7 +31,7 @@ namespace ns {
 // NB  buckets of 4 entries per wave   FB  foreign postings per super-batch (<= 256: the owner index has 8 bits).
 // A driver lookup reads ONE bucket and stops unless the bucket is full and holds no match: with FB/NB <= 0.75
 // a full bucket is a < 1% event, so practically every lookup is a single ds_read_b128 for all 64 lanes.
-template <int NB, int FB, bool AND, int CB = 256>
+template <int NB, int FB, bool AND, int CB = 256, bool IMP = false>
 __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* __restrict__ terms, const DevSeg* __restrict__ segs,
                                             uint32_t* ent, float* vals, uint8_t* mcnt, uint64_t* cand, uint4* tab, uint32_t* aux,
                                             Hit* __restrict__ out_hits, uint32_t* __restrict__ out_nhits,
@@ -56,6 +56,9 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
     const bool fast_div = (__builtin_amdgcn_readfirstlane((int)it.whole) & 8) != 0;   // host: every idf and norm of this item is in the range where v_div_scale/v_div_fixup are the identity
     const gp_u2 postings = (gp_u2)seg.postings;
     const gp_f32 pnorm = (gp_f32)seg.pnorm;
+    // IMP: every list of this item has its term scores precomputed (same arithmetic, done once per list at
+    // ns_segment_build_impacts): the streams carry {docId, score bits}; no tf, no norm, no division here.
+    const gp_u2 stream = IMP ? (gp_u2)seg.impacts : postings;
 
     {
         const float4 sent4 = make_float4(__uint_as_float(kSentinelBits), __uint_as_float(kSentinelBits),
@@ -231,8 +234,8 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
                 const bool inb = p < total;
                 ftj[j] = inb ? ftj[j] : 0u;
                 pidx[j] = tab[ftj[j]].z + (inb ? p : 0u);
-                pst[j] = postings[pidx[j]];
-                nrm[j] = pnorm[pidx[j]];
+                pst[j] = stream[pidx[j]];
+                nrm[j] = IMP ? 0.0f : pnorm[pidx[j]];
                 pst[j].x = inb ? pst[j].x : 0xFFFFFFFFu;   // docId ~0 is never <= hi
             }
             // ---- cursors: the first NOT-taken posting of a window publishes the new cursor ----
@@ -294,7 +297,12 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
                     num[j] = __uint_as_float(te.x) * (tf * (1.2f + 1.0f));
                     wqv[j] = __uint_as_float(te.y);
                 }
-                ns_div_n<FE>(fx, num, den, fast_div);
+                if (IMP) {
+#pragma unroll
+                    for (int j = 0; j < FE; j++) fx[j] = __uint_as_float(pst[j].y);
+                } else {
+                    ns_div_n<FE>(fx, num, den, fast_div);
+                }
 #pragma unroll
                 for (int j = 0; j < FE; j++) fx[j] = wqv[j] * fx[j];
             }
@@ -381,14 +389,14 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
             const uint32_t remd = d_end - d_cur;
             if (remd == 0) break;
             const uint32_t n = min(remd, (uint32_t)(DE * 64));
-            const gp_u2 sp = postings + d_cur;
+            const gp_u2 sp = stream + d_cur;
             const gp_f32 np = pnorm + d_cur;
             nat_u2 ps[DE];
             float nr[DE];
 #pragma unroll
             for (int j = 0; j < DE; j++) {
                 ps[j] = sp[j * 64 + lane];
-                nr[j] = np[j * 64 + lane];
+                nr[j] = IMP ? 0.0f : np[j * 64 + lane];
             }
             uint32_t cnt = 0, r_hits = 0;
             float dx[DE];
@@ -416,7 +424,12 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
                     den[j] = tf + nr[j];
                     num[j] = d_idf * (tf * (1.2f + 1.0f));
                 }
-                ns_div_n<DE>(dx, num, den, fast_div);
+                if (IMP) {
+#pragma unroll
+                    for (int j = 0; j < DE; j++) dx[j] = __uint_as_float(ps[j].y);
+                } else {
+                    ns_div_n<DE>(dx, num, den, fast_div);
+                }
 #pragma unroll
                 for (int j = 0; j < DE; j++) dx[j] = d_wq * dx[j];
             }

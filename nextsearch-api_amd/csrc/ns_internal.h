@@ -15,6 +15,7 @@ struct DevSeg {
     const uint2* postings;   // {docId, tf} pairs, all inverted files of the segment back to back
     const float* pnorm;      // per POSTING: norm[docId] (streams next to the posting; no dependent gather)
     const float* norm;       // per doc: k1*((1-b) + b*(doc_len/avgdl))   (src/api_engine.cpp:478)
+    const uint2* impacts;    // optional {docId, fp32 bits of the BM25 term score}, index-aligned with `postings` (ns_segment_build_impacts); nullptr if never built
     uint64_t     n_postings;
     uint32_t     n_docs;
     uint32_t     n_tiles;    // ceil(n_docs / tile_docs)

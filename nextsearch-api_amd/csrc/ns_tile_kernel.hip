@@ -22,7 +22,7 @@
 
 namespace ns {
 
-template <int TD, bool AND, int CB = 256>
+template <int TD, bool AND, int CB = 256, bool IMP = false>
 __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* __restrict__ terms, const DevSeg* __restrict__ segs,
                                             float* vals, uint8_t* mcnt, uint64_t* cand,
                                             Hit* __restrict__ out_hits, uint32_t* __restrict__ out_nhits,
@@ -38,6 +38,7 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
     const bool fast_div = (__builtin_amdgcn_readfirstlane((int)it.whole) & 8) != 0;   // see ns_div_short
     const gp_u2 postings = (gp_u2)seg.postings;
     const gp_f32 pnorm = (gp_f32)seg.pnorm;
+    const gp_u2 stream = IMP ? (gp_u2)seg.impacts : postings;   // IMP: {docId, precomputed term score bits} (see dscore_body)
 
     const float4 sent4 = make_float4(__uint_as_float(kSentinelBits), __uint_as_float(kSentinelBits),
                                      __uint_as_float(kSentinelBits), __uint_as_float(kSentinelBits));
@@ -85,12 +86,12 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
     uint32_t pf_start = 0xFFFFFFFFu, pf_n = 0;   // the prefetched round: absolute posting index of its first posting, size
 #define NS_ISSUE(PS, NR, start, nn_)                                                               \
     {                                                                                              \
-        const gp_u2 sp_ = postings + (start);                                                      \
+        const gp_u2 sp_ = stream + (start);                                                        \
         const gp_f32 np_ = pnorm + (start);                                                        \
         _Pragma("unroll") for (int j = 0; j < E; j++) {                                            \
             if ((uint32_t)(j * 64) >= (nn_)) continue;   /* uniform: chunk beyond this round */    \
             PS[j] = sp_[j * 64 + lane];                                                            \
-            NR[j] = np_[j * 64 + lane];                                                            \
+            if (!IMP) NR[j] = np_[j * 64 + lane];                                                  \
         }                                                                                          \
     }
 #define NS_ROUND_SIZE(rem_, want_) min(min((rem_), (uint32_t)(E * 64)), max((want_), 64u))
@@ -177,7 +178,8 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
                         den_[jj] = tf + nr[j];                                                     \
                         num_[jj] = idf * (tf * (1.2f + 1.0f));                                     \
                     }                                                                              \
-                    ns_div_n<NJ>(q_, num_, den_, fast_div);                                        \
+                    if (IMP) { _Pragma("unroll") for (int jj = 0; jj < (NJ); jj++) q_[jj] = __uint_as_float(ps[(J0) + jj].y); } \
+                    else ns_div_n<NJ>(q_, num_, den_, fast_div);                                   \
                     _Pragma("unroll") for (int jj = 0; jj < (NJ); jj++) x[(J0) + jj] = q_[jj];       \
                     /* read-add-write on the doc's slot; all reads of the round first (docIds of one term are */ \
                     /* distinct).  The slot index is masked: a corrupt (unsorted) list cannot leave the tile. */ \
@@ -339,7 +341,7 @@ __global__ void __launch_bounds__(256) k_tscore(const DevWItem* __restrict__ ite
 // unequal length per workgroup ~12 % of the wave slots sat idle mid-kernel.  One item per workgroup.
 constexpr int kUscoreWavesPerBlock = 1;
 
-template <int HK, int FB, bool AND, int CB, int TMAX>
+template <int HK, int FB, bool AND, int CB, int TMAX, bool IMP = false>
 __global__ void __launch_bounds__(64 * kUscoreWavesPerBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) k_uscore(const DevWItem* __restrict__ items, uint32_t n_items,
                                                 const DevTerm* __restrict__ terms, const DevSeg* __restrict__ segs,
                                                 Hit* __restrict__ out_hits, uint32_t* __restrict__ out_nhits,
@@ -360,13 +362,13 @@ __global__ void __launch_bounds__(64 * kUscoreWavesPerBlock) __attribute__((amdg
     const bool thin = (it.whole & 4u) != 0;   // the non-driver lists are thin: smallest foreign budget
     it.whole &= 9u;   // bit 0: whole segment, bit 3: short division
     if (thin)
-        dscore_body<HK / 2, 64, AND, CB>(it, terms, segs, s_tbl[wave], s_vals[wave], s_mcnt[wave], s_cand[wave],
+        dscore_body<HK / 2, 64, AND, CB, IMP>(it, terms, segs, s_tbl[wave], s_vals[wave], s_mcnt[wave], s_cand[wave],
                                  s_tab[wave], s_aux[wave], out_hits, out_nhits, out_found, K, lane);
     else if (tiles)
-        tscore_body<2 * HK, AND, CB>(it, terms, segs, reinterpret_cast<float*>(s_tbl[wave]), s_mcnt[wave], s_cand[wave],
+        tscore_body<2 * HK, AND, CB, IMP>(it, terms, segs, reinterpret_cast<float*>(s_tbl[wave]), s_mcnt[wave], s_cand[wave],
                                  out_hits, out_nhits, out_found, K, lane);
     else
-        dscore_body<HK / 2, FB, AND, CB>(it, terms, segs, s_tbl[wave], s_vals[wave], s_mcnt[wave], s_cand[wave],
+        dscore_body<HK / 2, FB, AND, CB, IMP>(it, terms, segs, s_tbl[wave], s_vals[wave], s_mcnt[wave], s_cand[wave],
                                  s_tab[wave], s_aux[wave], out_hits, out_nhits, out_found, K, lane);
 }
 

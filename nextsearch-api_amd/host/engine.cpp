@@ -82,6 +82,29 @@ bool Engine::reload() {
 }
 
 // Query preparation (tokenise, stop-words, lexicon probes, idf: src/api_engine.cpp:388-397,:454-461) for
+bool Engine::build_impacts() {
+    if (!ctx_) { err_ = "no device context"; return false; }
+    for (size_t sid = 0; sid < segments.size(); sid++) {
+        const auto& seg = segments[sid];
+        std::vector<uint64_t> off;
+        std::vector<uint32_t> cnt;
+        std::vector<float> idf;
+        off.reserve(seg.lex.size()); cnt.reserve(seg.lex.size()); idf.reserve(seg.lex.size());
+        for (const auto& kv : seg.lex) {
+            const nsx::LexEntry& e = kv.second;
+            if (e.df == 0 || e.count == 0) continue;   // never scored (src/api_engine.cpp:458)
+            off.push_back(seg.list_byte_offset(e));
+            cnt.push_back(e.count);
+            idf.push_back(bm25_idf(seg.N, e.df));   // the idf build_refs_range hands to the device for this list
+        }
+        int rc = ns_segment_build_impacts(ctx_, dev_segs_[sid], off.data(), cnt.data(), idf.data(), (uint32_t)off.size());
+        if (rc != NS_OK) { err_ = std::string("ns_segment_build_impacts: ") + ns_last_error(ctx_); return false; }
+    }
+    return true;
+}
+
+void Engine::use_impacts(bool on) { if (ctx_) ns_ctx_use_impacts(ctx_, on ? 1 : 0); }
+
 // queries [q0, q1); `refs` receives the term refs of those queries, qd[q].term_begin is relative to it.
 void Engine::build_refs_range(const std::vector<std::string>& queries, size_t q0, size_t q1, std::vector<ns_query_desc>& qd,
                               std::vector<ns_term_ref>& refs, std::vector<uint8_t>& usable) const {

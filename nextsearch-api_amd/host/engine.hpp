@@ -56,6 +56,10 @@ public:
     Engine& operator=(const Engine&) = delete;
 
     bool reload();                                              // include/api_engine.hpp:65
+    // Optional: per-posting term scores for every list of every lexicon, built on the device
+    // (ns_segment_build_impacts); searches then read {docId, score} instead of {docId, tf} + norm.  Same results.
+    bool build_impacts();
+    void use_impacts(bool on);
     std::string search(const std::string& query, int k);        // include/api_engine.hpp:66 (JSON text, dump(2) layout)
     bool search_hits(const std::string& query, int k, uint32_t flags, SearchResult& out);
     bool search_batch(const std::vector<std::string>& queries, int k, uint32_t flags, std::vector<SearchResult>& out);

@@ -217,6 +217,13 @@ extern "C" int nsh_engine_search_batch(nsh_engine* e, const char* const* queries
     return 0;
 }
 
+extern "C" int nsh_engine_build_impacts(nsh_engine* e) {
+    if (!e) return -1;
+    if (!e->eng.build_impacts()) { e->err = e->eng.last_error(); return -1; }
+    return 0;
+}
+extern "C" void nsh_engine_use_impacts(nsh_engine* e, int on) { if (e) e->eng.use_impacts(on != 0); }
+
 extern "C" int nsh_engine_prepare(nsh_engine* e, const char* const* queries, uint32_t n_queries, int k, uint32_t flags,
                                   ns_batch** out) {
     if (!e || !out) return -1;

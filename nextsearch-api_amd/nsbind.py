@@ -17,6 +17,7 @@ HOST_LIB_PATH = os.path.join(HERE, "libnextsearch_host.so")
 NS_OK = 0
 NS_FLAG_OR = 0
 NS_FLAG_AND = 1
+NS_INFO_IMPACTS = 0x100
 NS_MAX_K = 100
 
 
@@ -53,7 +54,7 @@ HIP_SYMBOLS = [
     "ns_ctx_create", "ns_ctx_destroy", "ns_ctx_set_stream", "ns_last_error", "ns_device_name",
     "ns_segment_upload", "ns_segment_release", "ns_search_batch", "ns_batch_prepare",
     "ns_batch_bind_outputs", "ns_batch_run", "ns_batch_sync", "ns_batch_fetch", "ns_batch_get_info",
-    "ns_batch_destroy", "ns_set_tuning",
+    "ns_batch_destroy", "ns_set_tuning", "ns_segment_build_impacts", "ns_ctx_use_impacts",
 ]
 HOST_SYMBOLS = [
     "nsh_gen_index", "nsh_engine_open", "nsh_engine_close", "nsh_engine_error", "nsh_engine_ctx",
@@ -61,6 +62,7 @@ HOST_SYMBOLS = [
     "nsh_engine_segment_doc_len", "nsh_engine_segment_postings", "nsh_engine_lookup", "nsh_bm25_idf",
     "nsh_base_terms", "nsh_engine_build_refs", "nsh_engine_search_json", "nsh_free",
     "nsh_engine_search_batch", "nsh_engine_prepare", "nsh_engine_doc_metadata", "nsh_engine_hits_to_json", "nsh_engine_search_batch_json",
+    "nsh_engine_build_impacts", "nsh_engine_use_impacts",
 ]
 
 _hip = None
@@ -85,6 +87,8 @@ def hip_lib():
         L.ns_device_name.restype = C.c_char_p
         L.ns_segment_upload.argtypes = [vp, u32, u32, C.c_float, vp, vp, u64, C.POINTER(vp)]
         L.ns_segment_release.argtypes = [vp, vp]
+        L.ns_segment_build_impacts.argtypes = [vp, vp, vp, vp, vp, u32]
+        L.ns_ctx_use_impacts.argtypes = [vp, i32]
         L.ns_search_batch.argtypes = [vp, vp, vp, u32, u32, vp, vp, vp, u32]
         L.ns_batch_prepare.argtypes = [vp, vp, vp, u32, u32, u32, C.POINTER(vp)]
         L.ns_batch_bind_outputs.argtypes = [vp, vp, vp, vp]
@@ -140,6 +144,9 @@ def host_lib():
         L.nsh_engine_doc_metadata.argtypes = [vp, u32, u32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]
         L.nsh_engine_hits_to_json.argtypes = [vp, C.c_char_p, i32, i32, u64, vp, u32, C.POINTER(vp)]
         L.nsh_engine_search_batch_json.argtypes = [vp, C.POINTER(C.c_char_p), u32, i32, C.POINTER(vp), vp]
+        L.nsh_engine_build_impacts.argtypes = [vp]
+        L.nsh_engine_use_impacts.argtypes = [vp, i32]
+        L.nsh_engine_use_impacts.restype = None
         _host = L
     return _host
 
@@ -347,6 +354,14 @@ class Engine:
         if rc != 0:
             raise RuntimeError(f"prepare failed: {self.error()}")
         return Batch(b, len(queries), clamp_k(k))
+
+    def build_impacts(self):
+        """Precompute every list's per-posting term scores on the device (optional second posting stream)."""
+        if self._L.nsh_engine_build_impacts(self.h) != 0:
+            raise RuntimeError(f"build_impacts failed: {self.error()}")
+
+    def use_impacts(self, on):
+        self._L.nsh_engine_use_impacts(self.h, 1 if on else 0)
 
     def set_tuning(self, variant=0, min_items=0, split_postings=0):
         rc = hip_lib().ns_set_tuning(self.ctx, variant, min_items, split_postings)

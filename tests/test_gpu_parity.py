@@ -346,6 +346,124 @@ def test_lone_query_wide_merge_ties_and_thresholds():
     L.ns_ctx_destroy(ctx)
 
 
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_impact_stream_equals_oracle_and_reference_golden(name, golden_index):
+    """The optional second posting stream ({docId, precomputed term score}; ns_segment_build_impacts) must
+    change nothing: same bytes as the oracle and as the real reference's captured output, in OR and AND
+    mode, for every golden index; and the batches must really have read it (NS_INFO_IMPACTS)."""
+    g, d, _ = golden_index(name)
+    eng, ora = nsbind.Engine(d, 0), orc.Oracle(d)
+    try:
+        queries = g["queries"]
+        plain = {k: eng.search_batch(queries, k) for k in (1, 10, 100)}
+        b = eng.prepare(queries, 10)
+        assert not (b.info().flags & nsbind.NS_INFO_IMPACTS)
+        b.close()
+        eng.build_impacts()
+        b = eng.prepare(queries, 10)
+        assert b.info().flags & nsbind.NS_INFO_IMPACTS
+        b.close()
+        for k in (1, 10, 100):
+            gpu = eng.search_batch(queries, k)
+            assert_same(gpu, ora.search_batch(queries, k), queries, f"{name} impacts k={k}")
+            for a, c in zip(gpu, plain[k]):
+                assert a.tobytes() == c.tobytes()
+        assert_same(eng.search_batch(queries, 10, nsbind.NS_FLAG_AND), ora.search_batch(queries, 10, nsbind.NS_FLAG_AND), queries, f"{name} impacts AND")
+        for case in g["cases"]:
+            gh, gn, gf, gu = eng.search_batch(queries, case["k"])
+            for qi, ref in enumerate(case["results"]):
+                if ref["found"] < 0:
+                    continue
+                assert int(gf[qi]) == ref["found"]
+                assert [int(x) for x in gh[qi, : gn[qi]]["score"].view(np.uint32)] == [h[2] for h in ref["hits"]]
+        # lone queries and forced fine splitting go through the same bodies
+        eng.set_tuning(0, 4096, 300)
+        assert_same(eng.search_batch(queries[:20], 10), ora.search_batch(queries[:20], 10), queries[:20], f"{name} impacts split")
+        eng.set_tuning(0, 0, 0)
+        # switched off: back to the {docId, tf} stream
+        eng.use_impacts(False)
+        b = eng.prepare(queries, 10)
+        assert not (b.info().flags & nsbind.NS_INFO_IMPACTS)
+        b.close()
+    finally:
+        eng.close()
+        ora.close()
+
+
+def test_impact_stream_partial_registration_and_foreign_idf():
+    """Raw C-ABI: a batch reads impact streams only if EVERY list in it is registered with the bit-identical
+    idf; otherwise it takes the {docId, tf} path.  Either way the numpy restatement must be met."""
+    L = nsbind.hip_lib()
+    ctx = C.c_void_p()
+    assert L.ns_ctx_create(0, C.byref(ctx)) == 0
+    N = 200_000
+    rng = np.random.default_rng(21)
+    doc_len = rng.integers(20, 3000, size=N, dtype=np.uint32)
+    avgdl = float(np.float32(doc_len.astype(np.float64).mean()))
+    sizes = [60_000, 9_000, 300, 120_000, 17]
+    lists, payload = [], []
+    for n in sizes:
+        docs = np.sort(rng.choice(N, size=n, replace=False)).astype(np.uint32)
+        tfs = rng.integers(1, 30, size=n, dtype=np.uint32)
+        lists.append((docs, tfs))
+        payload.append(np.stack([docs, tfs], axis=1).astype(np.uint32).ravel())
+    flat = np.concatenate(payload)
+    offs = np.cumsum([0] + [len(p) * 4 for p in payload])[:-1].astype(np.uint64)
+    seg = C.c_void_p()
+    assert L.ns_segment_upload(ctx, 0, N, C.c_float(avgdl), doc_len.ctypes.data, flat.ctypes.data, flat.nbytes, C.byref(seg)) == 0, L.ns_last_error(ctx)
+    idfs = np.array([1.5, 3.25, 6.0, 0.75, 9.5], dtype=np.float32)
+    weights = [1.0, 0.5, 1.0, 1.0, 0.25]
+    queries = [[0, 3], [3, 0, 1], [1, 2, 4], [4], [2, 0, 3, 1, 4, 0], [3], [0, 1]]
+
+    def run(idf_of, expect_imp):
+        qd = np.zeros(len(queries), dtype=nsbind.QDESC_DTYPE)
+        refs = []
+        for qi, q in enumerate(queries):
+            qd[qi] = (len(refs), len(q))
+            for li in q:
+                refs.append((0, len(lists[li][0]), int(offs[li]), idf_of[li], weights[li]))
+        refs = np.array(refs, dtype=nsbind.TERM_DTYPE)
+        bh = C.c_void_p()
+        assert L.ns_batch_prepare(ctx, qd.ctypes.data, refs.ctypes.data, len(qd), 10, 0, C.byref(bh)) == 0
+        info = nsbind.NsBatchInfo()
+        assert L.ns_batch_get_info(bh, C.byref(info)) == 0
+        L.ns_batch_destroy(bh)
+        assert bool(info.flags & nsbind.NS_INFO_IMPACTS) == expect_imp
+        for k in (10, 100):
+            rc, hits, nhits, found = nsbind.search_batch_raw(ctx, qd, refs, k)
+            assert rc == 0, L.ns_last_error(ctx)
+            for qi, q in enumerate(queries):
+                acc = _np_bm25(lists, q, [idf_of[li] for li in q], [weights[li] for li in q], doc_len, avgdl)
+                order = sorted(acc.items(), key=lambda kv: (-float(kv[1]), kv[0]))[:k]
+                n = int(nhits[qi])
+                assert int(found[qi]) == len(acc) and n == len(order)
+                assert [int(x) for x in hits[qi, :n]["doc"]] == [x for x, _ in order], (qi, k, expect_imp)
+                np.testing.assert_array_equal(hits[qi, :n]["score"].view(np.uint32), np.array([v for _, v in order], dtype=np.float32).view(np.uint32))
+
+    cnts = np.array(sizes, dtype=np.uint32)
+    run(idfs, False)
+    # four of the five lists: a batch that touches list 4 cannot use the stream
+    assert L.ns_segment_build_impacts(ctx, seg, offs[:4].ctypes.data, cnts[:4].ctypes.data, idfs[:4].ctypes.data, 4) == 0, L.ns_last_error(ctx)
+    run(idfs, False)
+    assert L.ns_segment_build_impacts(ctx, seg, offs[4:].ctypes.data, cnts[4:].ctypes.data, idfs[4:].ctypes.data, 1) == 0, L.ns_last_error(ctx)
+    run(idfs, True)
+    other = idfs.copy()
+    other[3] = np.float32(0.8125)   # a caller-chosen idf the stream was not built with
+    run(other, False)
+    # re-registering the list with the new idf replaces its scores
+    assert L.ns_segment_build_impacts(ctx, seg, offs[3:4].ctypes.data, cnts[3:4].ctypes.data, other[3:4].ctypes.data, 1) == 0
+    run(other, True)
+    run(idfs, False)
+    # overlapping lists and lists outside the segment are rejected
+    bad_off = np.array([offs[0], offs[0] + 8], dtype=np.uint64)
+    bad_cnt = np.array([10, 10], dtype=np.uint32)
+    assert L.ns_segment_build_impacts(ctx, seg, bad_off.ctypes.data, bad_cnt.ctypes.data, idfs[:2].ctypes.data, 2) != 0
+    big = np.array([flat.nbytes - 8], dtype=np.uint64)
+    assert L.ns_segment_build_impacts(ctx, seg, big.ctypes.data, bad_cnt[:1].ctypes.data, idfs[:1].ctypes.data, 1) != 0
+    assert L.ns_segment_release(ctx, seg) == 0
+    L.ns_ctx_destroy(ctx)
+
+
 def test_many_terms_per_query(engines):
     """More scored terms than one wave-pass handles (64) and than the reference's expansion cap (40)."""
     g, eng, ora = engines("mid1")
@@ -407,6 +525,19 @@ def test_full_size_1m_docs_properties_and_sample(index_factory):
             for i in idx[:12]:
                 lone = eng.search_batch([queries[i]], K, flags)
                 assert_same(lone, (hits[i:i + 1], nhits[i:i + 1], found[i:i + 1], usable[i:i + 1]), [queries[i]], cfg + " lone")
+        # the optional impact stream changes no byte of either full batch
+        plain = {}
+        for cfg in ("cfg5", "cfg3", "cfg2"):
+            gen, Q, K, flags, _ = workloads.WORKLOADS[cfg]
+            plain[cfg] = eng.search_batch(gen(Q), K, flags)
+        eng.build_impacts()
+        for cfg in ("cfg5", "cfg3", "cfg2"):
+            gen, Q, K, flags, _ = workloads.WORKLOADS[cfg]
+            b = eng.prepare(gen(Q), K, flags)
+            assert b.info().flags & nsbind.NS_INFO_IMPACTS
+            b.close()
+            for a, c in zip(eng.search_batch(gen(Q), K, flags), plain[cfg]):
+                assert a.tobytes() == c.tobytes(), cfg
     finally:
         eng.close()
         ora.close()

@@ -81,15 +81,18 @@ def main():
     ap.add_argument("--split", type=int, default=0)
     ap.add_argument("--laws", default="")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--impacts", action="store_true", help="build the optional impact streams first")
     args = ap.parse_args()
     tmp = tempfile.TemporaryDirectory(prefix="ns_law_")
     idx = os.path.join(tmp.name, "index")
     nsbind.gen_index(idx, 1, 1_000_000, 65536, 1337, False)
     eng = nsbind.Engine(idx, 0)
     eng.set_tuning(args.variant, 0, args.split)
+    if args.impacts:
+        eng.build_impacts()
     L = laws()
     names = [n for n in args.laws.split(",") if n] or list(L.keys())
-    print(f"variant={args.variant} split={args.split}")
+    print(f"variant={args.variant} split={args.split} impacts={args.impacts}")
     print(f"{'law':>14} {'Q':>6} {'post/q':>9} {'items':>7} {'kern_ms':>9} {'ns/post':>8} {'GB/s':>8} {'frac':>6}")
     for n in names:
         qs, k = L[n]
