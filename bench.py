@@ -41,6 +41,7 @@ def parse_args():
     ap.add_argument("--split", type=int, default=0, help="postings per work item (0 = library default)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--index-dir", default="", help="reuse/generate the index here instead of a temp dir")
+    ap.add_argument("--no-impact-leg", action="store_true", help="skip the extra measurement over the optional impact streams (profiling runs)")
     return ap.parse_args()
 
 
@@ -158,6 +159,40 @@ def main():
     fd = l_found.cpu().numpy()
     assert (nh == np.minimum(fd, K)).all(), "result sanity check failed"
 
+    # Extra leg (N=1, reported next to the headline, never as `value`): the same batch over the optional
+    # impact streams ({docId, precomputed term score}; ns_segment_build_impacts).  Same K steps, same
+    # timing; the result tensors must equal the headline run's byte for byte.
+    impact_leg = None
+    if n_gpus == 1 and args.variant == 0 and not args.no_impact_leg:
+        t0 = time.perf_counter()
+        eng.build_impacts()
+        build_s = time.perf_counter() - t0
+        b2 = eng.prepare(queries, K, flags)
+        i_hits, i_nhits, i_found = torch.zeros_like(l_hits), torch.zeros_like(l_nhits), torch.zeros_like(l_found)
+        b2.bind_outputs(i_hits.data_ptr(), i_nhits.data_ptr(), i_found.data_ptr())
+        for _ in range(args.warmup):
+            b2.run(timed=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            b2.run(timed=True)
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t0
+        b2.sync()
+        inf2 = b2.info()
+        same = bool(torch.equal(i_hits, l_hits) and torch.equal(i_nhits, l_nhits) and torch.equal(i_found, l_found))
+        assert inf2.flags & nsbind.NS_INFO_IMPACTS, "the impact leg did not read the impact streams"
+        assert same, "impact-stream results differ from the {docId, tf} path"
+        k2 = inf2.sum_score_kernel_ms / max(inf2.timed_runs, 1)
+        impact_leg = {
+            "what": "same batch, postings read as {docId, precomputed fp32 term score} (optional second stream, built once per list)",
+            "value": Q * args.steps / el2, "unit": "queries/s", "ms_per_step": el2 / args.steps * 1e3,
+            "kernel_ms": k2, "achieved": inf2.algo_bytes / (k2 * 1e-3) / 1e9 if k2 > 0 else 0.0,
+            "frac": (inf2.algo_bytes / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS) if k2 > 0 else 0.0,
+            "build_s": build_s, "identical_results": same,
+        }
+        b2.close()
+
     if rank == 0:
         score_ms = info.sum_score_kernel_ms / max(info.timed_runs, 1)
         total_ms = info.sum_total_ms / max(info.timed_runs, 1)
@@ -215,6 +250,8 @@ def main():
             cb = cpu_baseline(index_dir, queries, K, args.cpu_seconds)
             if cb is not None:
                 line["cpu_baseline"] = cb
+        if impact_leg is not None:
+            line["impact_stream"] = impact_leg
         print(json.dumps(line), flush=True)
 
     batch.close()
