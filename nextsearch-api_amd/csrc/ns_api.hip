@@ -498,8 +498,15 @@ static constexpr size_t kStageMaxBytes = 256ull << 20;   // larger batches uploa
 static constexpr size_t kPullUploadBytes = 256 << 10;     // uploads up to this size are pulled by a kernel instead of the DMA engine
 static constexpr size_t kHostResultBytes = 64 << 10;      // result arrays up to this size live in pinned host memory
 
+// Block sizes are quantised (powers of two from 64 KB to 64 MB, multiples of 16 MB above) so that a serving loop's
+// batches of slightly different shape reuse each other's blocks instead of going to hipMalloc.
+static size_t pool_quantise(size_t n) {
+    if (n <= (64u << 10)) return 64u << 10;
+    if (n <= (64u << 20)) { size_t q = 64u << 10; while (q < n) q <<= 1; return q; }
+    return (n + (16u << 20) - 1) & ~(size_t)((16u << 20) - 1);
+}
 static hipError_t pool_alloc(ns_ctx* ctx, void** out, size_t n) {
-    n = (std::max<size_t>(n, 1) + 255) & ~(size_t)255;
+    n = pool_quantise(n);
     size_t best = (size_t)-1;
     for (size_t i = 0; i < ctx->pool.size(); i++)
         if (ctx->pool[i].n >= n && ctx->pool[i].n <= 2 * n + 4096 && (best == (size_t)-1 || ctx->pool[i].n < ctx->pool[best].n)) best = i;
@@ -521,7 +528,7 @@ static hipError_t pool_alloc(ns_ctx* ctx, void** out, size_t n) {
 // caller has synchronised the stream: nothing in flight uses the block
 static void pool_free(ns_ctx* ctx, void* p, size_t n) {
     if (!p) return;
-    n = (std::max<size_t>(n, 1) + 255) & ~(size_t)255;
+    n = pool_quantise(n);
     if (ctx->pool_bytes + n > kPoolMaxBytes || ctx->pool.size() >= 64) { (void)hipFree(p); return; }
     ctx->pool.push_back({p, n});
     ctx->pool_bytes += n;
