@@ -152,6 +152,19 @@ void ns_batch_destroy(ns_batch* b);
  * of work items below which groups are additionally split across doc ranges.  split_postings: a
  * (query, segment) group is split into doc ranges of about this much estimated work (variant 0: units
  * of one streamed posting, default 98304 for K <= 32 and 131072 above; other variants: postings). */
+/* Index inversion (the step before the path): replaces the per-term std::vector<Posting> +
+ * std::sort of the reference's `lexicon` tool (src/lexicon.cpp:52-128).
+ *   doc_term_counts[d]  number of (termId, tf) pairs of document d (forward.bin's per-document `cnt`, :63)
+ *   pairs               the u32 {termId, tf} pairs of all documents back to back, in file order (:66-67)
+ *   n_terms             size of the term dictionary; pairs with termId >= n_terms are dropped (:69)
+ * Outputs (host memory): df_out[n_terms] = postings per term; postings_out (capacity n_pairs * 8 bytes) receives
+ * the {docId, tf} lists in termId order, each sorted by docId (equal docIds keep file order) — i.e. the
+ * reference's inverted_bNNN.bin files concatenated in barrel order; *kept_out = number of postings written;
+ * device_ms_out (optional) = HIP-event time of the device part, copies excluded. */
+int ns_invert_forward(ns_ctx* ctx, const uint32_t* doc_term_counts, uint32_t n_docs, const uint32_t* pairs,
+                      uint64_t n_pairs, uint32_t n_terms, uint32_t* df_out, void* postings_out, uint64_t* kept_out,
+                      float* device_ms_out);
+
 int  ns_set_tuning(ns_ctx* ctx, uint32_t variant, uint32_t min_items, uint32_t split_postings);
 
 #ifdef __cplusplus

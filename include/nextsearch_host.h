@@ -30,6 +30,13 @@ void nsh_engine_close(nsh_engine* e);
 const char* nsh_engine_error(nsh_engine* e);
 ns_ctx* nsh_engine_ctx(nsh_engine* e);
 
+/* The reference's `lexicon <SEGMENT_DIR>` tool (src/lexicon.cpp) with the inversion on the device
+ * (ns_invert_forward): reads <seg>/terms.bin + forward.bin, writes barrels.bin, lexicon_bNNN.bin and
+ * inverted_bNNN.bin byte for byte as the reference does.  0 on success; nsh_invert_error() otherwise. */
+int nsh_invert_segment(const char* seg_dir, int device, uint64_t* pairs, uint64_t* kept, float* device_ms,
+                       double* call_s, double* total_s);
+const char* nsh_invert_error(void);
+
 /* Optional impact streams for every list of every loaded lexicon (include/nextsearch_hip.h:
  * ns_segment_build_impacts / ns_ctx_use_impacts).  Not part of reload(): 8 B of HBM per posting. */
 int  nsh_engine_build_impacts(nsh_engine* e);

@@ -19,6 +19,7 @@
 #include "ns_wave_kernel.hip"
 #include "ns_driver_kernel.hip"
 #include "ns_tile_kernel.hip"
+#include "ns_invert.hip"
 
 using namespace ns;
 
@@ -1096,3 +1097,90 @@ extern "C" int ns_search_batch(ns_ctx* ctx, const ns_query_desc* queries, const 
     return rc;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// f3: forward.bin -> inverted lists (csrc/ns_invert.hip)
+extern "C" int ns_invert_forward(ns_ctx* ctx, const uint32_t* doc_term_counts, uint32_t n_docs, const uint32_t* pairs,
+                                 uint64_t n_pairs, uint32_t n_terms, uint32_t* df_out, void* postings_out, uint64_t* kept_out,
+                                 float* device_ms_out) {
+    if (!ctx) return fail(nullptr, NS_E_INVAL, "ns_invert_forward: ctx is NULL");
+    if ((n_docs && !doc_term_counts) || (n_pairs && !pairs) || (n_terms && !df_out) || !kept_out) return fail(ctx, NS_E_INVAL, "ns_invert_forward: null argument");
+    if (n_pairs >= (1ull << 32) - kIvTile) return fail(ctx, NS_E_INVAL, "ns_invert_forward: %llu pairs; this build indexes pairs with 32 bits (split the segment)", (unsigned long long)n_pairs);
+    if (n_terms == 0xFFFFFFFFu) return fail(ctx, NS_E_INVAL, "ns_invert_forward: n_terms too large");
+    *kept_out = 0;
+    if (device_ms_out) *device_ms_out = 0.0f;
+    std::vector<uint64_t> prefix((size_t)n_docs + 1, 0);
+    for (uint32_t d = 0; d < n_docs; d++) prefix[d + 1] = prefix[d] + doc_term_counts[d];
+    if (prefix[n_docs] != n_pairs) return fail(ctx, NS_E_INVAL, "ns_invert_forward: the per-document counts sum to %llu, not to n_pairs = %llu", (unsigned long long)prefix[n_docs], (unsigned long long)n_pairs);
+    if (n_terms) std::memset(df_out, 0, (size_t)n_terms * 4);
+    if (!n_pairs) return NS_OK;
+    if (!postings_out) return fail(ctx, NS_E_INVAL, "ns_invert_forward: postings_out is NULL");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint32_t n = (uint32_t)n_pairs;
+    const uint32_t n_tiles = (n + kIvTile - 1) / kIvTile;
+    const size_t m = (size_t)256 * n_tiles;                 // histogram counters per pass
+    const uint32_t scan_blocks = (uint32_t)((m + 1023) / 1024);
+    int bits = 1;
+    while (bits < 32 && (n_terms >> bits) != 0) bits++;     // the largest key is n_terms itself
+    const int passes = (bits + 7) / 8;
+
+    uint2 *d_pairs = nullptr, *d_vals[2] = {nullptr, nullptr};
+    uint32_t *d_keys[2] = {nullptr, nullptr}, *d_df = nullptr, *d_first = nullptr, *d_hist = nullptr, *d_sums = nullptr;
+    uint64_t* d_prefix = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipError_t e = hipSuccess;
+    auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    chk(hipMalloc((void**)&d_pairs, (size_t)n * 8));
+    chk(hipMalloc((void**)&d_vals[0], (size_t)n * 8));
+    chk(hipMalloc((void**)&d_vals[1], (size_t)n * 8));
+    chk(hipMalloc((void**)&d_keys[0], (size_t)n * 4));
+    chk(hipMalloc((void**)&d_keys[1], (size_t)n * 4));
+    chk(hipMalloc((void**)&d_df, (size_t)std::max<uint32_t>(n_terms, 1) * 4));
+    chk(hipMalloc((void**)&d_first, (size_t)std::max<uint32_t>(n_terms, 1) * 4));
+    chk(hipMalloc((void**)&d_hist, m * 4));
+    chk(hipMalloc((void**)&d_sums, (size_t)scan_blocks * 4));
+    chk(hipMalloc((void**)&d_prefix, prefix.size() * 8));
+    chk(hipEventCreate(&ev0));
+    chk(hipEventCreate(&ev1));
+    if (e == hipSuccess) {
+        chk(hipMemcpyAsync(d_pairs, pairs, (size_t)n * 8, hipMemcpyHostToDevice, st));
+        chk(hipMemcpyAsync(d_prefix, prefix.data(), prefix.size() * 8, hipMemcpyHostToDevice, st));
+        chk(hipMemsetAsync(d_df, 0, (size_t)std::max<uint32_t>(n_terms, 1) * 4, st));
+        chk(hipEventRecord(ev0, st));
+        const uint32_t eb = std::min<uint32_t>((n + 255) / 256, 1u << 16);
+        hipLaunchKernelGGL(k_iv_expand, dim3(eb), dim3(256), 0, st, d_pairs, d_prefix, n_docs, n, n_terms, d_keys[0], d_vals[0]);
+        int cur = 0;
+        for (int p = 0; p < passes; p++) {
+            const uint32_t shift = (uint32_t)p * 8;
+            hipLaunchKernelGGL(k_iv_hist, dim3(n_tiles), dim3(256), 0, st, d_keys[cur], n, shift, d_hist, n_tiles);
+            hipLaunchKernelGGL(k_iv_scan_sums, dim3(scan_blocks), dim3(256), 0, st, d_hist, (uint32_t)m, d_sums);
+            hipLaunchKernelGGL(k_iv_scan_top, dim3(1), dim3(1024), 0, st, d_sums, scan_blocks);
+            hipLaunchKernelGGL(k_iv_scan_apply, dim3(scan_blocks), dim3(256), 0, st, d_hist, (uint32_t)m, d_sums);
+            hipLaunchKernelGGL(k_iv_scatter, dim3(n_tiles), dim3(256), 0, st, d_keys[cur], d_vals[cur], d_keys[cur ^ 1], d_vals[cur ^ 1], n, shift, d_hist, n_tiles);
+            cur ^= 1;
+        }
+        if (n_terms) {
+            hipLaunchKernelGGL(k_iv_run_starts, dim3((n + 255) / 256), dim3(256), 0, st, d_keys[cur], n, n_terms, d_first);
+            hipLaunchKernelGGL(k_iv_run_lengths, dim3((n + 255) / 256), dim3(256), 0, st, d_keys[cur], n, n_terms, d_first, d_df);
+        }
+        chk(hipEventRecord(ev1, st));
+        chk(hipGetLastError());
+        if (n_terms) chk(hipMemcpyAsync(df_out, d_df, (size_t)n_terms * 4, hipMemcpyDeviceToHost, st));
+        chk(hipStreamSynchronize(st));
+        if (e == hipSuccess) {
+            uint64_t kept = 0;
+            for (uint32_t t = 0; t < n_terms; t++) kept += df_out[t];
+            *kept_out = kept;   // the dropped pairs carry the largest key: they sort behind every list
+            if (kept) chk(hipMemcpy(postings_out, d_vals[cur], (size_t)kept * 8, hipMemcpyDeviceToHost));
+            float ms = 0.0f;
+            if (e == hipSuccess && hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess && device_ms_out) *device_ms_out = ms;
+        }
+    }
+    (void)hipFree(d_pairs); (void)hipFree(d_vals[0]); (void)hipFree(d_vals[1]); (void)hipFree(d_keys[0]); (void)hipFree(d_keys[1]);
+    (void)hipFree(d_df); (void)hipFree(d_first); (void)hipFree(d_hist); (void)hipFree(d_sums); (void)hipFree(d_prefix);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? NS_E_NOMEM : NS_E_HIP, "ns_invert_forward: %s", hipGetErrorString(e));
+    return NS_OK;
+}

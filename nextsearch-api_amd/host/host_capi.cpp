@@ -1,4 +1,5 @@
 // C wrappers of include/nextsearch_host.h over nextsearch::Engine.
+#include "invert.hpp"
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -215,6 +216,25 @@ extern "C" int nsh_engine_search_batch(nsh_engine* e, const char* const* queries
         }
     }
     return 0;
+}
+
+// The reference's `lexicon <SEGMENT_DIR>` tool with the inversion on the device (host/invert.hpp).
+static thread_local std::string g_invert_err;
+extern "C" const char* nsh_invert_error() { return g_invert_err.c_str(); }
+extern "C" int nsh_invert_segment(const char* seg_dir, int device, uint64_t* pairs, uint64_t* kept, float* device_ms,
+                                  double* call_s, double* total_s) {
+    if (!seg_dir) return -1;
+    ns_ctx* ctx = nullptr;
+    if (ns_ctx_create(device, &ctx) != NS_OK) { g_invert_err = std::string("ns_ctx_create: ") + ns_last_error(nullptr); return -1; }
+    nsx::InvertStats st;
+    const bool ok = nsx::invert_segment(ctx, seg_dir, st, g_invert_err);
+    ns_ctx_destroy(ctx);
+    if (pairs) *pairs = st.pairs;
+    if (kept) *kept = st.kept;
+    if (device_ms) *device_ms = st.device_ms;
+    if (call_s) *call_s = st.call_s;
+    if (total_s) *total_s = st.total_s;
+    return ok ? 0 : -1;
 }
 
 extern "C" int nsh_engine_build_impacts(nsh_engine* e) {

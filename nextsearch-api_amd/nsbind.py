@@ -55,6 +55,7 @@ HIP_SYMBOLS = [
     "ns_segment_upload", "ns_segment_release", "ns_search_batch", "ns_batch_prepare",
     "ns_batch_bind_outputs", "ns_batch_run", "ns_batch_sync", "ns_batch_fetch", "ns_batch_get_info",
     "ns_batch_destroy", "ns_set_tuning", "ns_segment_build_impacts", "ns_ctx_use_impacts",
+    "ns_invert_forward",
 ]
 HOST_SYMBOLS = [
     "nsh_gen_index", "nsh_engine_open", "nsh_engine_close", "nsh_engine_error", "nsh_engine_ctx",
@@ -62,7 +63,7 @@ HOST_SYMBOLS = [
     "nsh_engine_segment_doc_len", "nsh_engine_segment_postings", "nsh_engine_lookup", "nsh_bm25_idf",
     "nsh_base_terms", "nsh_engine_build_refs", "nsh_engine_search_json", "nsh_free",
     "nsh_engine_search_batch", "nsh_engine_prepare", "nsh_engine_doc_metadata", "nsh_engine_hits_to_json", "nsh_engine_search_batch_json",
-    "nsh_engine_build_impacts", "nsh_engine_use_impacts",
+    "nsh_engine_build_impacts", "nsh_engine_use_impacts", "nsh_invert_segment", "nsh_invert_error",
 ]
 
 _hip = None
@@ -89,6 +90,7 @@ def hip_lib():
         L.ns_segment_release.argtypes = [vp, vp]
         L.ns_segment_build_impacts.argtypes = [vp, vp, vp, vp, vp, u32]
         L.ns_ctx_use_impacts.argtypes = [vp, i32]
+        L.ns_invert_forward.argtypes = [vp, vp, u32, vp, u64, u32, vp, vp, C.POINTER(u64), vp]
         L.ns_search_batch.argtypes = [vp, vp, vp, u32, u32, vp, vp, vp, u32]
         L.ns_batch_prepare.argtypes = [vp, vp, vp, u32, u32, u32, C.POINTER(vp)]
         L.ns_batch_bind_outputs.argtypes = [vp, vp, vp, vp]
@@ -144,6 +146,8 @@ def host_lib():
         L.nsh_engine_doc_metadata.argtypes = [vp, u32, u32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]
         L.nsh_engine_hits_to_json.argtypes = [vp, C.c_char_p, i32, i32, u64, vp, u32, C.POINTER(vp)]
         L.nsh_engine_search_batch_json.argtypes = [vp, C.POINTER(C.c_char_p), u32, i32, C.POINTER(vp), vp]
+        L.nsh_invert_segment.argtypes = [C.c_char_p, i32, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.nsh_invert_error.restype = C.c_char_p
         L.nsh_engine_build_impacts.argtypes = [vp]
         L.nsh_engine_use_impacts.argtypes = [vp, i32]
         L.nsh_engine_use_impacts.restype = None
@@ -367,6 +371,19 @@ class Engine:
         rc = hip_lib().ns_set_tuning(self.ctx, variant, min_items, split_postings)
         if rc != NS_OK:
             raise RuntimeError(hip_lib().ns_last_error(self.ctx).decode())
+
+
+def invert_segment(seg_dir, device=0):
+    """The reference's `lexicon <SEGMENT_DIR>` step with the inversion on the device; returns a stats dict."""
+    pairs, kept, ms, call_s, total_s = u64_(), u64_(), C.c_float(), C.c_double(), C.c_double()
+    rc = host_lib().nsh_invert_segment(str(seg_dir).encode(), device, C.byref(pairs), C.byref(kept), C.byref(ms), C.byref(call_s), C.byref(total_s))
+    if rc != 0:
+        raise RuntimeError(f"invert_segment failed: {host_lib().nsh_invert_error().decode()}")
+    return {"pairs": pairs.value, "kept": kept.value, "device_ms": ms.value, "call_s": call_s.value, "total_s": total_s.value}
+
+
+def u64_():
+    return C.c_uint64()
 
 
 def search_batch_raw(ctx, qd, refs, k, flags=NS_FLAG_OR):

@@ -124,7 +124,42 @@ def make_meta_fixture(outdir):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def make_invert_fixture(outdir):
+    """Index inversion: a small forward.bin / terms.bin pair (committed as base64: a fixture is
+    inputs + expected outputs) and the sha256 of every file the REAL `lexicon` tool (oracle/_ref/lexicon)
+    writes for it."""
+    import base64
+    import hashlib
+    import shutil
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import forward_gen
+    import invert_oracle
+    tool = os.path.join(ROOT, "oracle", "_ref", "lexicon")
+    if not os.path.exists(tool):
+        sys.exit("oracle/_ref/lexicon missing: run `make -C oracle ref` where /root/reference is mounted")
+    tmp = tempfile.mkdtemp(prefix="ns_golden_inv_")
+    try:
+        seg = os.path.join(tmp, "seg")
+        pairs = forward_gen.write_inputs(seg, 400, 900, 18, 20261)
+        inputs = {f: base64.b64encode(open(os.path.join(seg, f), "rb").read()).decode() for f in ("terms.bin", "forward.bin")}
+        subprocess.run([tool, seg], check=True, stderr=subprocess.DEVNULL)
+        outs = {}
+        for f in invert_oracle.output_files():
+            b = open(os.path.join(seg, f), "rb").read()
+            outs[f] = {"bytes": len(b), "sha256": hashlib.sha256(b).hexdigest()}
+        with open(os.path.join(outdir, "invert1.json"), "w") as fh:
+            json.dump({"what": "oracle/_ref/lexicon (the reference's src/lexicon.cpp, built as it lies) on the inputs below",
+                       "generator": "forward_gen.write_inputs(seg, 400, 900, 18, 20261)", "pairs": pairs,
+                       "inputs_base64": inputs, "outputs": outs}, fh, indent=0)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "invert":
+        make_invert_fixture(os.path.join(ROOT, "tests", "golden"))
+        return
     if not os.path.exists(orc.REF_DRIVER):
         sys.exit("oracle/_ref/ref_driver missing: run `make -C oracle ref` where /root/reference is mounted")
     outdir = os.path.join(ROOT, "tests", "golden")

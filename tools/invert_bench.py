@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Index inversion: forward.bin -> inverted lists on the device, timed next to the reference's
+own `lexicon` tool (oracle/_ref/lexicon, when it travelled to this box) or the numpy oracle.  GPU box only.
+Prints one JSON line: pairs/s of the device part, its algorithmic bytes (16 B per pair: {termId, tf} in,
+{docId, tf} out) against the HBM roofline, and the host-inclusive times."""
+import argparse
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "nextsearch-api_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import forward_gen  # noqa: E402
+import nsbind  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--docs", type=int, default=300_000)
+    ap.add_argument("--terms", type=int, default=65_536)
+    ap.add_argument("--mean", type=int, default=80)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+    tmp = tempfile.mkdtemp(prefix="ns_inv_")
+    try:
+        seg = os.path.join(tmp, "seg")
+        t0 = time.perf_counter()
+        pairs = forward_gen.write_inputs(seg, args.docs, args.terms, args.mean, 7)
+        print(f"# generated {pairs} pairs in {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
+        best = None
+        for _ in range(args.reps + 1):      # first call warms the code objects up
+            st = nsbind.invert_segment(seg)
+            if best is None or st["device_ms"] < best["device_ms"]:
+                best = st
+        cpu = None
+        if not args.no_cpu:
+            ref = os.path.join(ROOT, "oracle", "_ref", "lexicon")
+            seg2 = os.path.join(tmp, "seg2")
+            os.makedirs(seg2)
+            for f in ("terms.bin", "forward.bin"):
+                shutil.copy(os.path.join(seg, f), seg2)
+            t0 = time.perf_counter()
+            if os.path.exists(ref):
+                subprocess.run([ref, seg2], check=True, stderr=subprocess.DEVNULL)
+                kind = "reference"
+            else:
+                import invert_oracle
+                invert_oracle.lexicon_tool(seg2)
+                kind = "port"
+            dt = time.perf_counter() - t0
+            same = all(open(os.path.join(seg, f), "rb").read() == open(os.path.join(seg2, f), "rb").read()
+                       for f in ["barrels.bin"] + ["inverted_b%03u.bin" % b for b in range(64)] + ["lexicon_b%03u.bin" % b for b in range(64)])
+            cpu = {"value": pairs / dt, "unit": "pairs/s", "cores": 1, "kind": kind, "seconds": dt,
+                   "sample": "the same forward.bin, files in -> files out", "identical_files": same}
+        gbs = 16.0 * pairs / (best["device_ms"] * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "index inversion, (termId, tf) pairs per second (device part)", "value": pairs / (best["device_ms"] * 1e-3),
+            "unit": "pairs/s", "pairs": pairs, "docs": args.docs, "terms": args.terms, "device_ms": best["device_ms"],
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+                         "algo_bytes": 16 * pairs},
+            "host_inclusive": {"ns_invert_forward_s": best["call_s"], "files_in_to_files_out_s": best["total_s"]},
+            "cpu_baseline": cpu}), flush=True)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
