@@ -1123,7 +1123,7 @@ extern "C" int ns_invert_forward(ns_ctx* ctx, const uint32_t* doc_term_counts, u
     const uint32_t scan_blocks = (uint32_t)((m + 1023) / 1024);
     int bits = 1;
     while (bits < 32 && (n_terms >> bits) != 0) bits++;     // the largest key is n_terms itself
-    const int passes = (bits + 7) / 8;
+    int passes = (bits + 7) / 8;
 
     uint2 *d_pairs = nullptr, *d_vals[2] = {nullptr, nullptr};
     uint32_t *d_keys[2] = {nullptr, nullptr}, *d_df = nullptr, *d_first = nullptr, *d_hist = nullptr, *d_sums = nullptr;
@@ -1147,9 +1147,18 @@ extern "C" int ns_invert_forward(ns_ctx* ctx, const uint32_t* doc_term_counts, u
         chk(hipMemcpyAsync(d_pairs, pairs, (size_t)n * 8, hipMemcpyHostToDevice, st));
         chk(hipMemcpyAsync(d_prefix, prefix.data(), prefix.size() * 8, hipMemcpyHostToDevice, st));
         chk(hipMemsetAsync(d_df, 0, (size_t)std::max<uint32_t>(n_terms, 1) * 4, st));
+        chk(hipMemsetAsync(d_sums, 0, 4, st));   // k_iv_expand counts the dropped pairs here before the scans use it
         chk(hipEventRecord(ev0, st));
-        const uint32_t eb = std::min<uint32_t>((n + 255) / 256, 1u << 16);
-        hipLaunchKernelGGL(k_iv_expand, dim3(eb), dim3(256), 0, st, d_pairs, d_prefix, n_docs, n, n_terms, d_keys[0], d_vals[0]);
+        hipLaunchKernelGGL(k_iv_expand, dim3(n_tiles), dim3(256), 0, st, d_pairs, d_prefix, n_docs, n, n_terms, d_keys[0], d_vals[0], d_sums);
+        // the key n_terms exists only if some pair was dropped: without it the keys are < n_terms (one bit, often one pass, less)
+        uint32_t dropped = 0;
+        chk(hipMemcpyAsync(&dropped, d_sums, 4, hipMemcpyDeviceToHost, st));
+        chk(hipStreamSynchronize(st));
+        if (e == hipSuccess && dropped == 0 && n_terms > 1) {
+            bits = 1;
+            while (bits < 32 && ((n_terms - 1) >> bits) != 0) bits++;
+            passes = (bits + 7) / 8;
+        }
         int cur = 0;
         for (int p = 0; p < passes; p++) {
             const uint32_t shift = (uint32_t)p * 8;

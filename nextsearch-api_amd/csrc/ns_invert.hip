@@ -8,7 +8,8 @@
 // ceil(log2(n_terms + 1) / 8) passes (2 for a 65 536-term vocabulary, 3 up to 16 M terms):
 //
 //   k_iv_expand   pair i -> key = termId (n_terms for the ids the reference drops, :70), value = {docId, tf};
-//                 docId by binary search in the prefix sums of the per-document counts
+//                 docIds from the prefix sums of the per-document counts (boundaries marked per tile in LDS);
+//                 counts the dropped pairs: without any, the keys need one bit less (often one pass less)
 //   per pass:     k_iv_hist (LDS histogram per 4096-pair tile, written digit-major) -> exclusive scan of the
 //                 256 x tiles counters -> k_iv_scatter (stable ranks: wave-level match masks from 8 ballots,
 //                 per-wave digit counters in LDS, waves of a tile ordered by a 256-thread prefix)
@@ -27,21 +28,70 @@ namespace ns {
 constexpr int kIvItems = 16;                 // pairs per thread per tile
 constexpr int kIvTile = 256 * kIvItems;      // pairs per workgroup
 
+// One workgroup per tile of 4096 pairs.  The documents that START inside the tile mark their first pair in
+// LDS (an empty document shares its position with the next one: the largest docId wins, as the pair belongs
+// to the last document that starts at or before it); a running maximum then gives every pair its docId.
+// Two binary searches per tile (its first and last pair) instead of one per pair.
 __global__ void __launch_bounds__(256) k_iv_expand(const uint2* __restrict__ pairs, const uint64_t* __restrict__ doc_prefix,
                                                    uint32_t n_docs, uint32_t n_pairs, uint32_t n_terms,
-                                                   uint32_t* __restrict__ keys, uint2* __restrict__ vals) {
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_pairs; i += gridDim.x * 256) {
-        // the document that holds pair i: the last d with doc_prefix[d] <= i (documents may be empty)
+                                                   uint32_t* __restrict__ keys, uint2* __restrict__ vals, uint32_t* __restrict__ n_dropped) {
+    __shared__ uint32_t s_doc[kIvTile];
+    __shared__ uint32_t s_ends[2];
+    __shared__ uint32_t s_wmax[4];
+    __shared__ uint32_t s_drop;
+    const uint32_t tile0 = blockIdx.x * (uint32_t)kIvTile;
+    const uint32_t count = min((uint32_t)kIvTile, n_pairs - tile0);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int s = 0; s < kIvItems; s++) s_doc[s * 256 + threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_drop = 0;
+    if (threadIdx.x < 2) {   // the document that holds pair i: the last d with doc_prefix[d] <= i
+        const uint64_t i = (uint64_t)tile0 + (threadIdx.x ? count - 1 : 0u);
         uint32_t lo = 0, hi = n_docs;
         while (lo < hi) {
             const uint32_t mid = lo + ((hi - lo) >> 1);
-            if (doc_prefix[mid + 1] <= (uint64_t)i) lo = mid + 1; else hi = mid;
+            if (doc_prefix[mid + 1] <= i) lo = mid + 1; else hi = mid;
         }
-        const uint2 p = pairs[i];   // {termId, tf}
-        const bool keep = p.x < n_terms;
-        keys[i] = keep ? p.x : n_terms;
-        vals[i] = make_uint2(lo, p.y);
+        s_ends[threadIdx.x] = lo;
     }
+    __syncthreads();
+    const uint32_t d0 = s_ends[0], d1 = s_ends[1];
+    if (threadIdx.x == 0) s_doc[0] = d0;
+    for (uint32_t d = d0 + 1 + threadIdx.x; d <= d1; d += 256) atomicMax(&s_doc[(uint32_t)(doc_prefix[d] - tile0)], d);
+    __syncthreads();
+    // running maximum: thread t owns positions [16t, 16t + 16)
+    uint32_t m[kIvItems], run = 0;
+#pragma unroll
+    for (int j = 0; j < kIvItems; j++) { run = max(run, s_doc[threadIdx.x * kIvItems + j]); m[j] = run; }
+    uint32_t inc = run;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        const uint32_t o = __shfl_up(inc, dd, 64);
+        if (lane >= dd) inc = max(inc, o);
+    }
+    if (lane == 63) s_wmax[w] = inc;
+    const uint32_t before_lane = __shfl_up(inc, 1, 64);
+    __syncthreads();
+    uint32_t before = lane ? before_lane : 0u;
+    for (int j = 0; j < w; j++) before = max(before, s_wmax[j]);
+#pragma unroll
+    for (int j = 0; j < kIvItems; j++) s_doc[threadIdx.x * kIvItems + j] = max(m[j], before);
+    __syncthreads();
+    uint32_t dropped = 0;
+#pragma unroll
+    for (int s = 0; s < kIvItems; s++) {
+        const uint32_t li = (uint32_t)s * 256 + threadIdx.x;
+        if (li < count) {
+            const uint2 p = pairs[tile0 + li];   // {termId, tf}
+            const bool keep = p.x < n_terms;
+            dropped += keep ? 0u : 1u;
+            keys[tile0 + li] = keep ? p.x : n_terms;
+            vals[tile0 + li] = make_uint2(s_doc[li], p.y);
+        }
+    }
+    if (dropped) atomicAdd(&s_drop, dropped);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_drop) atomicAdd(n_dropped, s_drop);
 }
 
 // df from the SORTED keys (a histogram by atomics serialises on the frequent terms: the most frequent one
@@ -146,24 +196,38 @@ __global__ void __launch_bounds__(256) k_iv_scan_apply(uint32_t* __restrict__ a,
 
 // Stable scatter of one tile.  Wave w owns the tile's pairs [w*1024, (w+1)*1024) in 16 steps of 64; inside a
 // step the pairs with the same digit find each other with 8 ballots; ranks continue from the wave's running
-// per-digit counter in LDS (LDS operations of one wave execute in order).
+// per-digit counter in LDS (LDS operations of one wave execute in order).  The tile is then put in digit
+// order IN LDS and leaves from there: consecutive lanes write consecutive addresses of a (tile, digit) run
+// (written straight from the ranks, every lane of a store hit a different run: 12-B writes scattered 256 ways).
 __global__ void __launch_bounds__(256) k_iv_scatter(const uint32_t* __restrict__ keys_in, const uint2* __restrict__ vals_in,
                                                     uint32_t* __restrict__ keys_out, uint2* __restrict__ vals_out, uint32_t n,
                                                     uint32_t shift, const uint32_t* __restrict__ tile_base /* scanned [256][n_tiles] */,
                                                     uint32_t n_tiles) {
     __shared__ uint32_t wcnt[4][256];
+    __shared__ uint32_t gdelta[256];     // where digit d's run of this tile starts in the output, minus its start in the tile
+    __shared__ uint32_t wtot[4];
+    __shared__ uint32_t s_key[kIvTile];
+    __shared__ uint2 s_val[kIvTile];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
     for (int j = 0; j < 4; j++) wcnt[j][threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * (uint32_t)kIvTile + (uint32_t)w * (64u * kIvItems);
+    const uint32_t tile0 = blockIdx.x * (uint32_t)kIvTile;
+    const uint32_t base = tile0 + (uint32_t)w * (64u * kIvItems);
     const uint64_t lt = (1ull << lane) - 1ull;
     uint32_t key[kIvItems], rank[kIvItems];
+    uint2 val[kIvItems];
 #pragma unroll
     for (int s = 0; s < kIvItems; s++) {
         const uint32_t idx = base + (uint32_t)s * 64 + (uint32_t)lane;
         const bool valid = idx < n;
         key[s] = valid ? keys_in[idx] : 0xFFFFFFFFu;
+        val[s] = valid ? vals_in[idx] : make_uint2(0u, 0u);
+    }
+#pragma unroll
+    for (int s = 0; s < kIvItems; s++) {
+        const uint32_t idx = base + (uint32_t)s * 64 + (uint32_t)lane;
+        const bool valid = idx < n;
         const uint32_t d = (key[s] >> shift) & 255u;
         uint64_t mask = __builtin_amdgcn_ballot_w64(valid);
 #pragma unroll
@@ -177,24 +241,46 @@ __global__ void __launch_bounds__(256) k_iv_scatter(const uint32_t* __restrict__
         if (valid && (mask & lt) == 0ull) wcnt[w][d] = prev + (uint32_t)__popcll(mask);   // the group's first lane
     }
     __syncthreads();
-    {   // thread d: where each wave's pairs of digit d start in the output
+    {   // thread d: digit d's start in the tile (exclusive scan of the digit totals), the waves' starts inside it
         const uint32_t d = threadIdx.x;
-        uint32_t run = tile_base[(size_t)d * n_tiles + blockIdx.x];
+        uint32_t c[4], tot = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t c = wcnt[j][d];
-            wcnt[j][d] = run;
-            run += c;
+        for (int j = 0; j < 4; j++) { c[j] = wcnt[j][d]; tot += c[j]; }
+        uint32_t inc = tot;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const uint32_t o = __shfl_up(inc, dd, 64);
+            if (lane >= dd) inc += o;
         }
+        if (lane == 63) wtot[w] = inc;
+        __syncthreads();
+        uint32_t ex = inc - tot;
+        for (int j = 0; j < w; j++) ex += wtot[j];
+        gdelta[d] = tile_base[(size_t)d * n_tiles + blockIdx.x] - ex;
+        uint32_t run = ex;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { wcnt[j][d] = run; run += c[j]; }
     }
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < kIvItems; s++) {
         const uint32_t idx = base + (uint32_t)s * 64 + (uint32_t)lane;
         if (idx < n) {
-            const uint32_t pos = wcnt[w][(key[s] >> shift) & 255u] + rank[s];
-            keys_out[pos] = key[s];
-            vals_out[pos] = vals_in[idx];
+            const uint32_t lp = wcnt[w][(key[s] >> shift) & 255u] + rank[s];
+            s_key[lp] = key[s];
+            s_val[lp] = val[s];
+        }
+    }
+    __syncthreads();
+    const uint32_t count = min((uint32_t)kIvTile, n - tile0);
+#pragma unroll
+    for (int s = 0; s < kIvItems; s++) {
+        const uint32_t i = (uint32_t)s * 256 + threadIdx.x;
+        if (i < count) {
+            const uint32_t k = s_key[i];
+            const uint32_t pos = gdelta[(k >> shift) & 255u] + i;
+            keys_out[pos] = k;
+            vals_out[pos] = s_val[i];
         }
     }
 }
