@@ -152,6 +152,16 @@ void ns_batch_destroy(ns_batch* b);
  * of work items below which groups are additionally split across doc ranges.  split_postings: a
  * (query, segment) group is split into doc ranges of about this much estimated work (variant 0: units
  * of one streamed posting, default 98304 for K <= 32 and 131072 above; other variants: postings). */
+/* Segment-sharded multi-GPU (the alternative to query sharding for an index that outgrows one
+ * GPU's HBM): rank r holds a subset of the segments and scores ALL queries over it; the fixed-size per-rank rows
+ * are all-gathered rank-major (hits [n_ranks][n_queries][k], nhits and found [n_ranks][n_queries]) and joined here
+ * into the one global heap of src/api_engine.cpp:434-435,485-492 (score desc, global seg asc, doc asc; found =
+ * sum, :495).  d_seg_map[r * seg_map_stride + local seg id] = the segment's position in the full manifest
+ * (NULL: ids are already global).  All pointers are device pointers; asynchronous on the ctx stream. */
+int ns_merge_rank_rows(ns_ctx* ctx, const void* d_hits, const void* d_nhits, const void* d_found, uint32_t n_ranks,
+                       uint32_t n_queries, uint32_t k, const uint32_t* d_seg_map, uint32_t seg_map_stride,
+                       void* d_out_hits, void* d_out_nhits, void* d_out_found);
+
 /* Index inversion (the step before the path): replaces the per-term std::vector<Posting> +
  * std::sort of the reference's `lexicon` tool (src/lexicon.cpp:52-128).
  *   doc_term_counts[d]  number of (termId, tf) pairs of document d (forward.bin's per-document `cnt`, :63)

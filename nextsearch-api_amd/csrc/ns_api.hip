@@ -1193,3 +1193,21 @@ extern "C" int ns_invert_forward(ns_ctx* ctx, const uint32_t* doc_term_counts, u
     if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? NS_E_NOMEM : NS_E_HIP, "ns_invert_forward: %s", hipGetErrorString(e));
     return NS_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Segment-sharded multi-GPU: join the all-gathered per-rank rows (k_merge_ranks).  Device pointers; asynchronous on the ctx stream.
+extern "C" int ns_merge_rank_rows(ns_ctx* ctx, const void* d_hits, const void* d_nhits, const void* d_found, uint32_t n_ranks,
+                                  uint32_t n_queries, uint32_t k, const uint32_t* d_seg_map, uint32_t seg_map_stride,
+                                  void* d_out_hits, void* d_out_nhits, void* d_out_found) {
+    if (!ctx) return fail(nullptr, NS_E_INVAL, "ns_merge_rank_rows: ctx is NULL");
+    if (n_ranks < 1 || n_ranks > 64) return fail(ctx, NS_E_INVAL, "ns_merge_rank_rows: %u ranks (1..64 supported)", n_ranks);
+    if (k < 1 || k > NS_MAX_K) return fail(ctx, NS_E_INVAL, "k=%u outside [1,%u]", k, NS_MAX_K);
+    if (!n_queries) return NS_OK;
+    if (!d_hits || !d_nhits || !d_found || !d_out_hits || !d_out_nhits || !d_out_found) return fail(ctx, NS_E_INVAL, "ns_merge_rank_rows: null buffer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_merge_ranks, dim3((n_queries + 3) / 4), dim3(256), 0, ctx->stream, (const Hit*)d_hits, (const uint32_t*)d_nhits,
+                       (const uint64_t*)d_found, n_ranks, n_queries, k, d_seg_map, seg_map_stride, (Hit*)d_out_hits, (uint32_t*)d_out_nhits,
+                       (uint64_t*)d_out_found);
+    HIPCHK(ctx, hipGetLastError());
+    return NS_OK;
+}

@@ -490,6 +490,68 @@ __global__ void __launch_bounds__(256) k_merge(const DevQuery* __restrict__ quer
     merge_rows_wave(q, pb, pc, part_hits, part_nhits, out_hits, out_nhits, out_found, found, K, heads, lane);
 }
 
+// Segment-sharded multi-GPU (SURVEY.md 8(e) alternative): every rank scored ALL queries over ITS segments; the
+// per-rank rows were all-gathered rank-major ([rank][query][K]).  One wave per query, lane r holds rank r's row
+// head; K rounds of wave argmax in the canonical order (score desc, GLOBAL seg asc, doc asc) rebuild the one
+// global heap of src/api_engine.cpp:434-435,485-492; `found` is the sum over ranks (:495 counts per segment).
+// seg_map[r * stride + local seg id] = the segment's id in the full manifest (nullptr: ids are already global).
+__global__ void __launch_bounds__(256) k_merge_ranks(const Hit* __restrict__ hits, const uint32_t* __restrict__ nhits,
+                                                     const uint64_t* __restrict__ found, uint32_t n_ranks, uint32_t n_queries, uint32_t K,
+                                                     const uint32_t* __restrict__ seg_map, uint32_t seg_map_stride,
+                                                     Hit* __restrict__ out_hits, uint32_t* __restrict__ out_nhits, uint64_t* __restrict__ out_found) {
+    const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (q >= n_queries) return;
+    const bool mine = (uint32_t)lane < n_ranks;
+    const size_t row = (size_t)lane * n_queries + q;
+    const uint32_t n = mine ? min(nhits[row], K) : 0u;
+    uint64_t f = mine ? found[row] : 0ull;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) f += __shfl_xor(f, d, 64);
+    const Hit* my = hits + row * K;
+    uint32_t h = 0, produced = 0;
+    Hit* oh = out_hits + (size_t)q * K;
+    for (; produced < K; produced++) {
+        uint32_t s = 0;
+        uint64_t id = ~0ull;
+        if (h < n) {
+            const Hit e = my[h];
+            const uint32_t gseg = seg_map ? seg_map[(size_t)lane * seg_map_stride + e.seg] : e.seg;
+            s = order_bits(e.score);
+            id = ((uint64_t)gseg << 32) | e.doc;
+        }
+        uint32_t ms = s;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) ms = max(ms, (uint32_t)__shfl_xor(ms, d, 64));
+        if (__ballot(h < n) == 0ull) break;
+        uint64_t mid = (h < n && s == ms) ? id : ~0ull;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const uint64_t o = __shfl_xor(mid, d, 64);
+            mid = o < mid ? o : mid;
+        }
+        if (h < n && s == ms && id == mid) {   // (seg, doc) pairs are unique across ranks: one winner
+            Hit w;
+            w.score = unorder_bits(ms);
+            w.seg = (uint32_t)(mid >> 32);
+            w.doc = (uint32_t)mid;
+            oh[produced] = w;
+            h++;
+        }
+    }
+    for (uint32_t i = produced + lane; i < K; i += 64) {
+        Hit w;
+        w.score = -__builtin_inff();
+        w.seg = 0xFFFFFFFFu;
+        w.doc = 0xFFFFFFFFu;
+        oh[i] = w;
+    }
+    if (lane == 0) {
+        out_nhits[q] = produced;
+        out_found[q] = f;
+    }
+}
+
 constexpr uint32_t kMergeCap = 2048;    // candidates held in LDS; more than that (mass ties) falls back to the tournament
 constexpr uint32_t kMergeBins = 2048;   // 11 bits per histogram pass
 constexpr uint32_t kMergeRegRows = 32;  // row heads cached per thread (a lone query has at most n_cus * 24 + a few rows)
