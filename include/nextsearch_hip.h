@@ -152,6 +152,20 @@ void ns_batch_destroy(ns_batch* b);
  * of work items below which groups are additionally split across doc ranges.  split_postings: a
  * (query, segment) group is split into doc ranges of about this much estimated work (variant 0: units
  * of one streamed posting, default 98304 for K <= 32 and 131072 above; other variants: postings). */
+/* Semantic query expansion's similarity search: SemanticIndex::most_similar_to_vec,
+ * src/semantic_embedding.cpp:104-145.  ns_sem_upload takes the row-major table of L2-normalised fp32 vectors
+ * (SemanticIndex::vecs, include/semantic_embedding.hpp:24).  ns_sem_topk: for each of n_q query vectors (host,
+ * n_q x dim) the up-to-topk rows with the largest dot product among rows that are not banned for that query
+ * (ban_off[n_q + 1] / ban_rows, may be NULL) and have sim >= min_sim — best first, ties to the smaller row;
+ * dot products are accumulated in index order in fp32 (the reference's bits).  rows_out / sims_out:
+ * n_q x topk (host), counts_out[q] = entries valid for query q.  topk <= 64. */
+typedef struct ns_sem ns_sem;
+int ns_sem_upload(ns_ctx* ctx, const float* vecs, uint32_t n_rows, uint32_t dim, ns_sem** out);
+int ns_sem_release(ns_ctx* ctx, ns_sem* sem);
+int ns_sem_topk(ns_ctx* ctx, ns_sem* sem, const float* qvecs, uint32_t n_q, uint32_t topk, float min_sim,
+                const uint32_t* ban_off, const uint32_t* ban_rows, uint32_t* rows_out, float* sims_out,
+                uint32_t* counts_out, float* device_ms_out);
+
 /* Segment-sharded multi-GPU (the alternative to query sharding for an index that outgrows one
  * GPU's HBM): rank r holds a subset of the segments and scores ALL queries over it; the fixed-size per-rank rows
  * are all-gathered rank-major (hits [n_ranks][n_queries][k], nhits and found [n_ranks][n_queries]) and joined here

@@ -20,6 +20,7 @@
 #include "ns_driver_kernel.hip"
 #include "ns_tile_kernel.hip"
 #include "ns_invert.hip"
+#include "ns_sem.hip"
 
 using namespace ns;
 
@@ -1209,5 +1210,118 @@ extern "C" int ns_merge_rank_rows(ns_ctx* ctx, const void* d_hits, const void* d
                        (const uint64_t*)d_found, n_ranks, n_queries, k, d_seg_map, seg_map_stride, (Hit*)d_out_hits, (uint32_t*)d_out_nhits,
                        (uint64_t*)d_out_found);
     HIPCHK(ctx, hipGetLastError());
+    return NS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// f4: semantic expansion's similarity search (csrc/ns_sem.hip)
+struct ns_sem {
+    ns_ctx* ctx = nullptr;
+    uint32_t rows = 0, dim = 0, rows_pad = 0;
+    float* d_vt = nullptr;   // [dim][rows_pad]
+};
+
+extern "C" int ns_sem_upload(ns_ctx* ctx, const float* vecs, uint32_t n_rows, uint32_t dim, ns_sem** out) {
+    if (!ctx) return fail(nullptr, NS_E_INVAL, "ns_sem_upload: ctx is NULL");
+    if (!out || !vecs || !n_rows || !dim) return fail(ctx, NS_E_INVAL, "ns_sem_upload: empty table or null argument");
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ns_sem* s = new ns_sem();
+    s->ctx = ctx; s->rows = n_rows; s->dim = dim; s->rows_pad = (n_rows + 63u) & ~63u;
+    float* d_in = nullptr;
+    hipError_t e = hipMalloc((void**)&s->d_vt, (size_t)dim * s->rows_pad * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_in, (size_t)n_rows * dim * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, vecs, (size_t)n_rows * dim * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_sem_transpose, dim3((s->rows_pad + 31) / 32, (dim + 31) / 32), dim3(256), 0, ctx->stream, d_in, s->d_vt, n_rows, dim, s->rows_pad);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_in);
+    if (e != hipSuccess) {
+        (void)hipFree(s->d_vt);
+        delete s;
+        return fail(ctx, e == hipErrorOutOfMemory ? NS_E_NOMEM : NS_E_HIP, "ns_sem_upload: %s", hipGetErrorString(e));
+    }
+    *out = s;
+    return NS_OK;
+}
+
+extern "C" int ns_sem_release(ns_ctx* ctx, ns_sem* sem) {
+    if (!ctx || !sem || sem->ctx != ctx) return fail(ctx, NS_E_INVAL, "ns_sem_release: table does not belong to this ctx");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(sem->d_vt);
+    delete sem;
+    return NS_OK;
+}
+
+extern "C" int ns_sem_topk(ns_ctx* ctx, ns_sem* sem, const float* qvecs, uint32_t n_q, uint32_t topk, float min_sim,
+                           const uint32_t* ban_off, const uint32_t* ban_rows, uint32_t* rows_out, float* sims_out,
+                           uint32_t* counts_out, float* device_ms_out) {
+    if (!ctx || !sem || sem->ctx != ctx) return fail(ctx, NS_E_INVAL, "ns_sem_topk: table does not belong to this ctx");
+    if (topk < 1 || topk > (uint32_t)kSemMaxK) return fail(ctx, NS_E_INVAL, "ns_sem_topk: topk=%u outside [1,%d]", topk, kSemMaxK);
+    if (device_ms_out) *device_ms_out = 0.0f;
+    if (!n_q) return NS_OK;
+    if (!qvecs || !rows_out || !sims_out || !counts_out) return fail(ctx, NS_E_INVAL, "ns_sem_topk: null argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint32_t dim = sem->dim, rows = sem->rows, rp = sem->rows_pad;
+    const uint32_t n_chunks = (rows + kSemChunk - 1) / kSemChunk, n_cand = n_chunks * topk;
+    const uint32_t n_groups = (n_q + kSemB - 1) / kSemB;
+    const uint32_t n_ban = ban_off ? ban_off[n_q] : 0;
+    // per-group ban offsets, rebased
+    std::vector<uint32_t> goff((size_t)n_groups * (kSemB + 1), 0), grows(std::max<uint32_t>(n_ban, 1), 0);
+    if (n_ban && !ban_rows) return fail(ctx, NS_E_INVAL, "ns_sem_topk: ban_rows is NULL");
+    if (n_ban) std::memcpy(grows.data(), ban_rows, (size_t)n_ban * 4);
+    for (uint32_t g = 0; g < n_groups; g++)
+        for (uint32_t b = 0; b <= (uint32_t)kSemB; b++) {
+            const uint32_t qi = std::min(g * kSemB + b, n_q);
+            goff[(size_t)g * (kSemB + 1) + b] = ban_off ? ban_off[qi] : 0;
+        }
+    std::vector<float> qpad((size_t)n_groups * kSemB * dim, 0.0f);
+    std::memcpy(qpad.data(), qvecs, (size_t)n_q * dim * 4);
+
+    float *d_q = nullptr, *d_sims = nullptr, *d_osims = nullptr;
+    uint32_t *d_goff = nullptr, *d_grows = nullptr, *d_orows = nullptr, *d_ocnt = nullptr;
+    uint64_t* d_cand = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipError_t e = hipSuccess;
+    auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    const size_t n_pad = (size_t)n_groups * kSemB;
+    chk(hipMalloc((void**)&d_q, qpad.size() * 4));
+    chk(hipMalloc((void**)&d_sims, (size_t)kSemB * rp * 4));
+    chk(hipMalloc((void**)&d_cand, (size_t)kSemB * n_cand * 8));
+    chk(hipMalloc((void**)&d_goff, goff.size() * 4));
+    chk(hipMalloc((void**)&d_grows, grows.size() * 4));
+    chk(hipMalloc((void**)&d_orows, n_pad * topk * 4));
+    chk(hipMalloc((void**)&d_osims, n_pad * topk * 4));
+    chk(hipMalloc((void**)&d_ocnt, n_pad * 4));
+    chk(hipEventCreate(&ev0));
+    chk(hipEventCreate(&ev1));
+    if (e == hipSuccess) {
+        chk(hipMemcpyAsync(d_q, qpad.data(), qpad.size() * 4, hipMemcpyHostToDevice, st));
+        chk(hipMemcpyAsync(d_goff, goff.data(), goff.size() * 4, hipMemcpyHostToDevice, st));
+        chk(hipMemcpyAsync(d_grows, grows.data(), grows.size() * 4, hipMemcpyHostToDevice, st));
+        chk(hipEventRecord(ev0, st));
+        for (uint32_t g = 0; g < n_groups; g++) {
+            hipLaunchKernelGGL(k_sem_sims, dim3((rows + 255) / 256), dim3(256), 0, st, sem->d_vt, rows, rp, dim, d_q + (size_t)g * kSemB * dim, d_sims);
+            hipLaunchKernelGGL(k_sem_chunk_topk, dim3(n_chunks, kSemB), dim3(256), 0, st, d_sims, rows, rp, min_sim, d_goff + (size_t)g * (kSemB + 1), d_grows, topk, n_chunks, d_cand);
+            hipLaunchKernelGGL(k_sem_final_topk, dim3(kSemB), dim3(256), 0, st, d_cand, n_cand, topk, d_orows + (size_t)g * kSemB * topk, d_osims + (size_t)g * kSemB * topk, d_ocnt + (size_t)g * kSemB);
+        }
+        chk(hipEventRecord(ev1, st));
+        chk(hipGetLastError());
+        chk(hipMemcpyAsync(rows_out, d_orows, (size_t)n_q * topk * 4, hipMemcpyDeviceToHost, st));
+        chk(hipMemcpyAsync(sims_out, d_osims, (size_t)n_q * topk * 4, hipMemcpyDeviceToHost, st));
+        chk(hipMemcpyAsync(counts_out, d_ocnt, (size_t)n_q * 4, hipMemcpyDeviceToHost, st));
+        chk(hipStreamSynchronize(st));
+        float ms = 0.0f;
+        if (e == hipSuccess && device_ms_out && hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) *device_ms_out = ms;
+    }
+    (void)hipFree(d_q); (void)hipFree(d_sims); (void)hipFree(d_cand); (void)hipFree(d_goff); (void)hipFree(d_grows);
+    (void)hipFree(d_orows); (void)hipFree(d_osims); (void)hipFree(d_ocnt);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? NS_E_NOMEM : NS_E_HIP, "ns_sem_topk: %s", hipGetErrorString(e));
     return NS_OK;
 }

@@ -55,7 +55,7 @@ HIP_SYMBOLS = [
     "ns_segment_upload", "ns_segment_release", "ns_search_batch", "ns_batch_prepare",
     "ns_batch_bind_outputs", "ns_batch_run", "ns_batch_sync", "ns_batch_fetch", "ns_batch_get_info",
     "ns_batch_destroy", "ns_set_tuning", "ns_segment_build_impacts", "ns_ctx_use_impacts",
-    "ns_invert_forward", "ns_merge_rank_rows",
+    "ns_invert_forward", "ns_merge_rank_rows", "ns_sem_upload", "ns_sem_release", "ns_sem_topk",
 ]
 HOST_SYMBOLS = [
     "nsh_gen_index", "nsh_engine_open", "nsh_engine_close", "nsh_engine_error", "nsh_engine_ctx",
@@ -90,6 +90,9 @@ def hip_lib():
         L.ns_segment_release.argtypes = [vp, vp]
         L.ns_segment_build_impacts.argtypes = [vp, vp, vp, vp, vp, u32]
         L.ns_ctx_use_impacts.argtypes = [vp, i32]
+        L.ns_sem_upload.argtypes = [vp, vp, u32, u32, C.POINTER(vp)]
+        L.ns_sem_release.argtypes = [vp, vp]
+        L.ns_sem_topk.argtypes = [vp, vp, vp, u32, u32, C.c_float, vp, vp, vp, vp, vp, vp]
         L.ns_merge_rank_rows.argtypes = [vp, vp, vp, vp, u32, u32, u32, vp, u32, vp, vp, vp]
         L.ns_invert_forward.argtypes = [vp, vp, u32, vp, u64, u32, vp, vp, C.POINTER(u64), vp]
         L.ns_search_batch.argtypes = [vp, vp, vp, u32, u32, vp, vp, vp, u32]

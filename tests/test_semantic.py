@@ -1,0 +1,83 @@
+"""Semantic query expansion (src/semantic_embedding.cpp).  Raw C-ABI: ns_sem_topk against a numpy
+restatement of most_similar_to_vec (:104-145) with the reference's sequential fp32 dot product (:11-15)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import nsbind
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def np_dot_rows(V, q):
+    """dot(q, V[r]) for every row, accumulated in index order with one fp32 rounding per multiply and per add."""
+    acc = np.zeros(V.shape[0], dtype=np.float32)
+    for i in range(V.shape[1]):
+        acc = (acc + (np.float32(q[i]) * V[:, i]).astype(np.float32)).astype(np.float32)
+    return acc
+
+
+def np_most_similar(V, q, topk, min_sim, banned):
+    sims = np_dot_rows(V, q)
+    ok = sims >= np.float32(min_sim)
+    if len(banned):
+        ok[np.asarray(sorted(banned), dtype=np.int64)] = False
+    rows = np.nonzero(ok)[0]
+    order = sorted(rows.tolist(), key=lambda r: (-float(sims[r]), r))[:topk]
+    return order, sims[order] if order else np.zeros(0, dtype=np.float32)
+
+
+def _normalised(rng, rows, dim):
+    V = rng.standard_normal((rows, dim)).astype(np.float32)
+    n = np.sqrt((V.astype(np.float64) ** 2).sum(axis=1))
+    return (V / n[:, None]).astype(np.float32)      # l2_normalize: double sum, (float)(x / n)  (:18-24)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,dim", [(20_000, 50), (8192, 300), (70_001, 64), (37, 10)])
+def test_sem_topk_equals_numpy_restatement(rows, dim):
+    L = nsbind.hip_lib()
+    ctx = C.c_void_p()
+    assert L.ns_ctx_create(0, C.byref(ctx)) == 0
+    rng = np.random.default_rng(rows + dim)
+    V = _normalised(rng, rows, dim)
+    # clusters, so that sims above the reference's 0.55 exist; duplicates, so that ties exist
+    for c in range(0, min(rows, 400), 7):
+        V[c + 1 if c + 1 < rows else c] = V[c]
+        for j in range(2, 6):
+            if c + j < rows:
+                w = V[c] + 0.25 * j * V[c + j]
+                V[c + j] = (w / np.sqrt((w.astype(np.float64) ** 2).sum())).astype(np.float32)
+    sem = C.c_void_p()
+    assert L.ns_sem_upload(ctx, V.ctypes.data, rows, dim, C.byref(sem)) == 0, L.ns_last_error(ctx)
+    n_q = 11 if rows > 100 else 3
+    qrows = rng.choice(min(rows, 400), size=n_q, replace=False)
+    Q = V[qrows].copy()
+    cen = Q[:3].sum(axis=0) / np.float32(3)
+    Q[-1] = (cen / np.sqrt((cen.astype(np.float64) ** 2).sum())).astype(np.float32)    # a centroid query (:193-204)
+    bans = [sorted({int(qrows[i]), int(qrows[(i + 1) % n_q])}) for i in range(n_q)]
+    ban_off = np.concatenate([[0], np.cumsum([len(b) for b in bans])]).astype(np.uint32)
+    ban_rows = np.array([r for b in bans for r in b], dtype=np.uint32)
+    for topk, min_sim in ((3, 0.55), (5, 0.55), (64, -2.0), (1, 0.9999)):
+        out_rows = np.zeros((n_q, topk), dtype=np.uint32)
+        out_sims = np.zeros((n_q, topk), dtype=np.float32)
+        cnt = np.zeros(n_q, dtype=np.uint32)
+        assert L.ns_sem_topk(ctx, sem, Q.ctypes.data, n_q, topk, C.c_float(min_sim), ban_off.ctypes.data, ban_rows.ctypes.data,
+                             out_rows.ctypes.data, out_sims.ctypes.data, cnt.ctypes.data, None) == 0, L.ns_last_error(ctx)
+        for qi in range(n_q):
+            want_rows, want_sims = np_most_similar(V, Q[qi], topk, min_sim, bans[qi])
+            assert int(cnt[qi]) == len(want_rows), (rows, topk, qi)
+            assert out_rows[qi, :len(want_rows)].tolist() == want_rows, (rows, topk, qi)
+            assert np.array_equal(out_sims[qi, :len(want_rows)].view(np.uint32), np.asarray(want_sims, dtype=np.float32).view(np.uint32))
+    # no ban lists at all
+    out_rows = np.zeros((n_q, 3), dtype=np.uint32); out_sims = np.zeros((n_q, 3), dtype=np.float32); cnt = np.zeros(n_q, dtype=np.uint32)
+    assert L.ns_sem_topk(ctx, sem, Q.ctypes.data, n_q, 3, C.c_float(0.55), None, None, out_rows.ctypes.data, out_sims.ctypes.data, cnt.ctypes.data, None) == 0
+    for qi in range(n_q):
+        want_rows, _ = np_most_similar(V, Q[qi], 3, 0.55, [])
+        assert out_rows[qi, :int(cnt[qi])].tolist() == want_rows
+    assert L.ns_sem_topk(ctx, sem, Q.ctypes.data, n_q, 65, C.c_float(0.5), None, None, out_rows.ctypes.data, out_sims.ctypes.data, cnt.ctypes.data, None) != 0
+    assert L.ns_sem_release(ctx, sem) == 0
+    L.ns_ctx_destroy(ctx)
