@@ -37,6 +37,14 @@ int nsh_invert_segment(const char* seg_dir, int device, uint64_t* pairs, uint64_
                        double* call_s, double* total_s);
 const char* nsh_invert_error(void);
 
+/* Semantic query expansion (src/api_engine.cpp:115-153,:409-417; src/semantic_embedding.cpp): reload() loads
+ * <index>/embeddings.vec|embeddings.txt|glove.txt|vectors.txt (or $EMBEDDINGS_PATH) for the lexicons' terms and
+ * uploads the table; every search then scores the expanded, weighted terms (similarity search on the device,
+ * ns_sem_topk).  nsh_engine_semantic_info: 1 if a table is loaded (+ rows, dim).  nsh_engine_expand: the weighted
+ * terms of one query, "term<TAB>%08x weight bits" per line in scoring order; free with nsh_free. */
+int nsh_engine_semantic_info(nsh_engine* e, uint32_t* rows, uint32_t* dim);
+int nsh_engine_expand(nsh_engine* e, const char* query, char** text_out);
+
 /* Optional impact streams for every list of every loaded lexicon (include/nextsearch_hip.h:
  * ns_segment_build_impacts / ns_ctx_use_impacts).  Not part of reload(): 8 B of HBM per posting. */
 int  nsh_engine_build_impacts(nsh_engine* e);

@@ -29,6 +29,8 @@ void Engine::release_device_segments() {
         for (ns_seg* s : dev_segs_)
             if (s) ns_segment_release(ctx_, s);
     dev_segs_.clear();
+    if (ctx_ && sem.dev) ns_sem_release(ctx_, sem.dev);
+    sem.dev = nullptr;
 }
 
 bool Engine::reload() {
@@ -78,6 +80,25 @@ bool Engine::reload() {
     segments = std::move(loaded);
     // metadata mapping (src/api_engine.cpp:110-113): absent file = no decoration, not an error
     meta.load(index_dir / "metadata.csv", segments);
+    // embeddings (src/api_engine.cpp:115-153): only the terms some lexicon holds; absent or unusable file = no expansion
+    sem.clear();
+    {
+        std::unordered_set<std::string> needed;
+        needed.reserve(250000);
+        for (const auto& seg : segments)
+            for (const auto& kv : seg.lex) needed.insert(kv.first);
+        nsx::fs::path emb;
+        if (const char* p = std::getenv("EMBEDDINGS_PATH")) {
+            emb = nsx::fs::path(p);
+        } else {
+            for (const char* c : {"embeddings.vec", "embeddings.txt", "glove.txt", "vectors.txt"})
+                if (nsx::fs::exists(index_dir / c)) { emb = index_dir / c; break; }
+        }
+        if (!emb.empty() && nsx::fs::exists(emb) && sem.load_from_text(emb, needed) && ctx_) {
+            int rc = ns_sem_upload(ctx_, sem.vecs.data(), (uint32_t)sem.terms.size(), (uint32_t)sem.dim, &sem.dev);
+            if (rc != NS_OK) { err_ = std::string("ns_sem_upload: ") + ns_last_error(ctx_); return false; }
+        }
+    }
     return true;
 }
 
@@ -107,16 +128,20 @@ void Engine::use_impacts(bool on) { if (ctx_) ns_ctx_use_impacts(ctx_, on ? 1 : 
 
 // queries [q0, q1); `refs` receives the term refs of those queries, qd[q].term_begin is relative to it.
 void Engine::build_refs_range(const std::vector<std::string>& queries, size_t q0, size_t q1, std::vector<ns_query_desc>& qd,
-                              std::vector<ns_term_ref>& refs, std::vector<uint8_t>& usable) const {
+                              std::vector<ns_term_ref>& refs, std::vector<uint8_t>& usable,
+                              const std::vector<nsx::WeightedTerms>* expanded) const {
     for (size_t q = q0; q < q1; q++) {
-        std::vector<std::string> terms = base_terms(queries[q]);
+        nsx::WeightedTerms own;
+        if (!expanded)   // weights: 1.0f per base term (src/api_engine.cpp:419-421)
+            for (auto& t : base_terms(queries[q])) own.emplace_back(std::move(t), 1.0f);
+        const nsx::WeightedTerms& terms = expanded ? (*expanded)[q] : own;
         qd[q].term_begin = (uint32_t)refs.size();
-        if (terms.empty() || segments.empty()) continue;   // src/api_engine.cpp:407
+        if (terms.empty() || segments.empty()) continue;   // src/api_engine.cpp:407, :424
         usable[q] = 1;
-        // weights: 1.0f per term (semantic expansion is out of scope; src/api_engine.cpp:419-421)
         for (uint32_t sid = 0; sid < segments.size(); sid++) {
             const auto& seg = segments[sid];
-            for (const auto& t : terms) {
+            for (const auto& tw : terms) {
+                const std::string& t = tw.first;
                 auto it = seg.lex.find(t);
                 if (it == seg.lex.end()) continue;           // :455
                 const nsx::LexEntry& e = it->second;
@@ -126,7 +151,7 @@ void Engine::build_refs_range(const std::vector<std::string>& queries, size_t q0
                 r.count = e.count;
                 r.byte_off = seg.list_byte_offset(e);
                 r.idf = bm25_idf(seg.N, e.df);
-                r.qweight = 1.0f;
+                r.qweight = tw.second;
                 refs.push_back(r);
             }
         }
@@ -143,13 +168,20 @@ void Engine::build_refs(const std::vector<std::string>& queries, std::vector<ns_
     qd.assign(Q, ns_query_desc{0, 0});
     usable.assign(Q, 0);
     refs.clear();
+    refs_failed_ = false;
+    std::vector<nsx::WeightedTerms> expanded;
+    const std::vector<nsx::WeightedTerms>* ex = nullptr;
+    if (sem.enabled) {   // src/api_engine.cpp:409-417: one device call per top-k size for the whole batch
+        if (!expand_queries(queries, expanded)) { refs_failed_ = true; return; }
+        ex = &expanded;
+    }
     unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
     nt = (unsigned)std::min<size_t>(nt, Q / 512);   // below ~512 queries per thread the spawn costs more than it saves
-    if (nt <= 1) { build_refs_range(queries, 0, Q, qd, refs, usable); return; }
+    if (nt <= 1) { build_refs_range(queries, 0, Q, qd, refs, usable, ex); return; }
     std::vector<std::vector<ns_term_ref>> part(nt);
     std::vector<std::thread> th;
     for (unsigned i = 0; i < nt; i++)
-        th.emplace_back([&, i]() { build_refs_range(queries, Q * i / nt, Q * (i + 1) / nt, qd, part[i], usable); });
+        th.emplace_back([&, i]() { build_refs_range(queries, Q * i / nt, Q * (i + 1) / nt, qd, part[i], usable, ex); });
     for (auto& t : th) t.join();
     size_t total = 0;
     for (auto& p : part) total += p.size();
@@ -161,6 +193,19 @@ void Engine::build_refs(const std::vector<std::string>& queries, std::vector<ns_
     }
 }
 
+bool Engine::expand_queries(const std::vector<std::string>& queries, std::vector<nsx::WeightedTerms>& out) const {
+    std::vector<std::vector<std::string>> qt(queries.size());
+    for (size_t q = 0; q < queries.size(); q++) qt[q] = base_terms(queries[q]);
+    if (!sem.enabled) {
+        out.assign(queries.size(), {});
+        for (size_t q = 0; q < queries.size(); q++)
+            for (auto& t : qt[q]) out[q].emplace_back(t, 1.0f);
+        return true;
+    }
+    if (!ctx_ || !sem.dev) { err_ = "embeddings are loaded but there is no device context: the similarity search has no CPU path"; return false; }
+    return sem.expand_batch(ctx_, qt, out, err_);
+}
+
 bool Engine::prepare(const std::vector<std::string>& queries, int k, uint32_t flags, ns_batch** out) {
     if (!ctx_) { err_ = "no device context: this engine has no CPU scoring path"; return false; }
     const int K = std::max(1, std::min(k, 100));   // src/api_engine.cpp:377
@@ -168,6 +213,7 @@ bool Engine::prepare(const std::vector<std::string>& queries, int k, uint32_t fl
     std::vector<ns_term_ref> refs;
     std::vector<uint8_t> usable;
     build_refs(queries, qd, refs, usable);
+    if (refs_failed_) return false;
     int rc = ns_batch_prepare(ctx_, qd.data(), refs.data(), (uint32_t)queries.size(), (uint32_t)K, flags, out);
     if (rc != NS_OK) { err_ = std::string("ns_batch_prepare: ") + ns_last_error(ctx_); return false; }
     return true;
@@ -182,6 +228,7 @@ bool Engine::search_batch(const std::vector<std::string>& queries, int k, uint32
     std::vector<ns_term_ref> refs;
     std::vector<uint8_t> usable;
     build_refs(queries, qd, refs, usable);
+    if (refs_failed_) return false;
     std::vector<ns_hit> hits(Q * (size_t)K);
     std::vector<uint32_t> nhits(Q);
     std::vector<uint64_t> found(Q);

@@ -21,6 +21,7 @@
 #include "../../include/nextsearch_hip.h"
 #include "index_format.hpp"
 #include "metadata.hpp"
+#include "semantic.hpp"
 
 namespace nextsearch {
 
@@ -48,6 +49,7 @@ public:
     std::vector<std::string> seg_names;
     std::vector<nsx::SegmentData> segments;
     nsx::MetadataTable meta;   // <index>/metadata.csv, parsed once at reload() (src/api_engine.cpp:110-113,:516-531)
+    nsx::SemanticTable sem;    // optional embeddings (src/api_engine.cpp:115-153): when loaded, every search expands its terms (:409-417)
 
     // device < 0: host-only (index + query preparation; every search call fails loudly)
     explicit Engine(int device = 0);
@@ -66,8 +68,12 @@ public:
 
     // Query preparation only: flattened term refs in the C-ABI's layout.
     // usable[q] == 0 marks the early-return case (no base terms, or no segments).
+    // `expanded`: the queries' weighted terms from semantic expansion (nullptr: base terms, weight 1.0)
     void build_refs_range(const std::vector<std::string>& queries, size_t q0, size_t q1, std::vector<ns_query_desc>& qd,
-                          std::vector<ns_term_ref>& refs, std::vector<uint8_t>& usable) const;
+                          std::vector<ns_term_ref>& refs, std::vector<uint8_t>& usable,
+                          const std::vector<nsx::WeightedTerms>* expanded = nullptr) const;
+    // The weighted query terms a search scores (base terms, or their semantic expansion when embeddings are loaded)
+    bool expand_queries(const std::vector<std::string>& queries, std::vector<nsx::WeightedTerms>& out) const;
     void build_refs(const std::vector<std::string>& queries, std::vector<ns_query_desc>& qd,
                     std::vector<ns_term_ref>& refs, std::vector<uint8_t>& usable) const;
     // Staged form used by bench.py: descriptors resident on the device, caller drives ns_batch_*.
@@ -81,10 +87,11 @@ public:
 
 private:
     void release_device_segments();
+    mutable bool refs_failed_ = false;   // build_refs could not run the device part of the expansion (err_ says why)
     int device_;
     ns_ctx* ctx_ = nullptr;
     std::vector<ns_seg*> dev_segs_;
-    std::string err_;
+    mutable std::string err_;
 };
 
 }  // namespace nextsearch

@@ -237,6 +237,32 @@ extern "C" int nsh_invert_segment(const char* seg_dir, int device, uint64_t* pai
     return ok ? 0 : -1;
 }
 
+// Semantic expansion (src/api_engine.cpp:409-417): rows/dim of the loaded embedding table (0/0: none), and the
+// weighted terms a query is scored with, one "term<TAB>fp32 weight bits in hex" line each, in scoring order.
+extern "C" int nsh_engine_semantic_info(nsh_engine* e, uint32_t* rows, uint32_t* dim) {
+    if (!e) return -1;
+    if (rows) *rows = e->eng.sem.enabled ? (uint32_t)e->eng.sem.terms.size() : 0;
+    if (dim) *dim = e->eng.sem.enabled ? (uint32_t)e->eng.sem.dim : 0;
+    return e->eng.sem.enabled ? 1 : 0;
+}
+extern "C" int nsh_engine_expand(nsh_engine* e, const char* query, char** text_out) {
+    if (!e || !query || !text_out) return -1;
+    std::vector<nsx::WeightedTerms> w;
+    if (!e->eng.expand_queries({std::string(query)}, w)) { e->err = e->eng.last_error(); return -1; }
+    std::string o;
+    char buf[16];
+    for (const auto& tw : w[0]) {
+        uint32_t bits;
+        std::memcpy(&bits, &tw.second, 4);
+        std::snprintf(buf, sizeof(buf), "%08x", bits);
+        o += tw.first; o += '\t'; o += buf; o += '\n';
+    }
+    *text_out = (char*)std::malloc(o.size() + 1);
+    if (!*text_out) return -1;
+    std::memcpy(*text_out, o.c_str(), o.size() + 1);
+    return 0;
+}
+
 extern "C" int nsh_engine_build_impacts(nsh_engine* e) {
     if (!e) return -1;
     if (!e->eng.build_impacts()) { e->err = e->eng.last_error(); return -1; }

@@ -64,6 +64,7 @@ HOST_SYMBOLS = [
     "nsh_base_terms", "nsh_engine_build_refs", "nsh_engine_search_json", "nsh_free",
     "nsh_engine_search_batch", "nsh_engine_prepare", "nsh_engine_doc_metadata", "nsh_engine_hits_to_json", "nsh_engine_search_batch_json",
     "nsh_engine_build_impacts", "nsh_engine_use_impacts", "nsh_invert_segment", "nsh_invert_error",
+    "nsh_engine_semantic_info", "nsh_engine_expand",
 ]
 
 _hip = None
@@ -152,6 +153,8 @@ def host_lib():
         L.nsh_engine_search_batch_json.argtypes = [vp, C.POINTER(C.c_char_p), u32, i32, C.POINTER(vp), vp]
         L.nsh_invert_segment.argtypes = [C.c_char_p, i32, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.nsh_invert_error.restype = C.c_char_p
+        L.nsh_engine_semantic_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
+        L.nsh_engine_expand.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
         L.nsh_engine_build_impacts.argtypes = [vp]
         L.nsh_engine_use_impacts.argtypes = [vp, i32]
         L.nsh_engine_use_impacts.restype = None
@@ -362,6 +365,20 @@ class Engine:
         if rc != 0:
             raise RuntimeError(f"prepare failed: {self.error()}")
         return Batch(b, len(queries), clamp_k(k))
+
+    def semantic_info(self):
+        rows, dim = C.c_uint32(), C.c_uint32()
+        on = self._L.nsh_engine_semantic_info(self.h, C.byref(rows), C.byref(dim))
+        return bool(on), rows.value, dim.value
+
+    def expand(self, query):
+        """[(term, fp32 weight bits)] a search scores for this query, in scoring order."""
+        out = C.c_void_p()
+        if self._L.nsh_engine_expand(self.h, query.encode(), C.byref(out)) != 0:
+            raise RuntimeError(f"expand failed: {self.error()}")
+        text = C.string_at(out).decode()
+        self._L.nsh_free(out)
+        return [(ln.split("\t")[0], int(ln.split("\t")[1], 16)) for ln in text.splitlines()]
 
     def build_impacts(self):
         """Precompute every list's per-posting term scores on the device (optional second posting stream)."""

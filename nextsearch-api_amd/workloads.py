@@ -157,3 +157,28 @@ def metadata_csv(n_docs_total, seed=11):
         if rng.random() < 0.01:
             lines.append(f'yy{i:08d},,,"A title with an embedded\nnewline, inside quotes",,,,,,2020,"C, D",,,,,,,http://y/{i},')
     return ("\n".join(lines) + "\n").encode("utf-8")
+
+
+def embeddings_text(vocab, dim=24, seed=5, clusters=0):
+    """A deterministic word-embedding text file for the synthetic vocabulary (term_name(1..vocab)), in the format
+    src/semantic_embedding.cpp:36-100 reads: optional "<count> <dim>" header, then "word v1 .. vD" lines.
+    Terms come in clusters (centre + noise) so that neighbours above the reference's min_sim 0.55 exist; the file
+    also holds words no lexicon has, a line with fewer than 10 values and a line of another dimension (all skipped
+    by the loader), and a repeated word (its second row is unreachable by name but still a neighbour)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    clusters = clusters or max(8, vocab // 6)
+    centres = rng.standard_normal((clusters, dim))
+    lines = ["%d %d" % (vocab + 40, dim)]
+    order = rng.permutation(vocab) + 1
+    for n, r in enumerate(order):
+        v = centres[int(r) % clusters] + rng.standard_normal(dim) * (0.25 + 0.5 * ((int(r) // clusters) % 3))
+        lines.append(term_name(int(r)) + " " + " ".join("%.6f" % x for x in v))
+        if n % 97 == 5:
+            lines.append("zz_notindexed_%d " % n + " ".join("%.6f" % x for x in rng.standard_normal(dim)))
+        if n == 11:
+            lines.append(term_name(int(order[3])) + " " + " ".join("%.6f" % x for x in rng.standard_normal(dim)))   # repeated word
+            lines.append(term_name(int(order[4])) + "x 0.1 0.2 0.3")                                                    # < 10 values
+            lines.append(term_name(int(order[5])) + "y " + " ".join("%.6f" % x for x in rng.standard_normal(dim + 3)))  # other dim
+            lines.append("")
+    return ("\n".join(lines) + "\n").encode("utf-8")

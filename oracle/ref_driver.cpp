@@ -32,6 +32,7 @@
 
 #include "api_engine.hpp"
 #include "api_segment.hpp"
+#include "textutil.hpp"
 
 using cord19::json;
 
@@ -51,7 +52,7 @@ static void drop_cache(cord19::Engine& e) {
 
 int main(int argc, char** argv) {
     if (argc < 6) {
-        std::fprintf(stderr, "usage: %s search|json|time <index_dir> <queries.txt> <K> <out|max_seconds>\n", argv[0]);
+        std::fprintf(stderr, "usage: %s search|json|expand|time <index_dir> <queries.txt> <K> <out|max_seconds>\n", argv[0]);
         return 2;
     }
     std::string mode = argv[1];
@@ -59,7 +60,7 @@ int main(int argc, char** argv) {
     std::string qpath = fs::absolute(argv[3]).string();
     int K = std::atoi(argv[4]);
     std::string last = argv[5];
-    std::string outpath = (mode == "search" || mode == "json") ? fs::absolute(last).string() : std::string();
+    std::string outpath = (mode == "search" || mode == "json" || mode == "expand") ? fs::absolute(last).string() : std::string();
 
     auto queries = read_lines(qpath);
 
@@ -108,6 +109,29 @@ int main(int argc, char** argv) {
                 std::fprintf(out, "J %zu\n", text.size());
                 std::fwrite(text.data(), 1, text.size(), out);
                 std::fputc('\n', out);
+            }
+            std::fclose(out);
+        } else if (mode == "expand") {
+            // the weighted terms Engine::search scores (src/api_engine.cpp:386-417), in scoring order
+            std::FILE* out = std::fopen(outpath.c_str(), "w");
+            if (!out) { std::perror("out"); return 1; }
+            std::fprintf(out, "S %d %zu %d\n", engine.sem.enabled ? 1 : 0, engine.sem.terms.size(), engine.sem.dim);
+            for (auto& q : queries) {
+                auto qtoks = tokenize(q);
+                std::vector<std::string> base_terms;
+                for (auto& t : qtoks) {
+                    if (t.size() < 2) continue;
+                    if (is_stopword(t)) continue;
+                    base_terms.push_back(t);
+                }
+                std::vector<std::pair<std::string, float>> w;
+                if (!base_terms.empty() && engine.sem.enabled) w = engine.sem.expand(base_terms, 3, 5, 0.55f, 0.6f, 40);
+                std::fprintf(out, "E %zu\n", w.size());
+                for (auto& tw : w) {
+                    uint32_t bits;
+                    std::memcpy(&bits, &tw.second, 4);
+                    std::fprintf(out, "%s\t%08x\n", tw.first.c_str(), bits);
+                }
             }
             std::fclose(out);
         } else if (mode == "time") {

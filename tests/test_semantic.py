@@ -81,3 +81,71 @@ def test_sem_topk_equals_numpy_restatement(rows, dim):
     assert L.ns_sem_topk(ctx, sem, Q.ctypes.data, n_q, 65, C.c_float(0.5), None, None, out_rows.ctypes.data, out_sims.ctypes.data, cnt.ctypes.data, None) != 0
     assert L.ns_sem_release(ctx, sem) == 0
     L.ns_ctx_destroy(ctx)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# End to end against the REAL reference (tests/golden/sem1.json, made by tools/gen_golden.py sem): an index with an
+# embeddings file next to it -> the table the loader keeps, the weighted terms a search scores (ORDER and weight
+# bits: the order is the fp32 accumulation order of the scores), and the hits.
+import hashlib
+import json
+
+import workloads
+
+
+def _sem_fixture(index_factory):
+    with open(os.path.join(ROOT, "tests", "golden", "sem1.json")) as f:
+        g = json.load(f)
+    p = g["params"]
+    d, _ = index_factory(p["n_segments"], p["docs_per_segment"], p["vocab"], p["seed"], p["legacy"])
+    emb = workloads.embeddings_text(p["vocab"], p["emb_dim"], p["emb_seed"])
+    assert hashlib.sha256(emb).hexdigest() == g["embeddings_sha256"], "the embeddings generator drifted from the golden's"
+    path = os.path.join(d, "embeddings.vec")
+    if not os.path.exists(path):
+        with open(path, "wb") as f:
+            f.write(emb)
+    return g, d, path
+
+
+def test_embedding_loader_equals_reference(index_factory):
+    """Host only: header line, words outside the lexicons, short and odd-dimension lines, a repeated word."""
+    g, d, path = _sem_fixture(index_factory)
+    try:
+        eng = nsbind.Engine(d, -1)
+        try:
+            on, rows, dim = eng.semantic_info()
+            assert (int(on), rows, dim) == (g["table"]["enabled"], g["table"]["rows"], g["table"]["dim"])
+            with pytest.raises(RuntimeError, match="no CPU"):      # the similarity search has no CPU path
+                eng.expand("covid vaccine")
+        finally:
+            eng.close()
+    finally:
+        os.remove(path)
+
+
+@pytest.mark.gpu
+def test_semantic_search_equals_reference(index_factory):
+    g, d, path = _sem_fixture(index_factory)
+    try:
+        eng = nsbind.Engine(d, 0)
+        try:
+            assert eng.semantic_info() == (True, g["table"]["rows"], g["table"]["dim"])
+            for q, want in zip(g["queries"], g["expand"]):
+                assert eng.expand(q) == [(t, b) for t, b in want], q
+            for case in g["cases"]:
+                gh, gn, gf, gu = eng.search_batch(g["queries"], case["k"])
+                for qi, ref in enumerate(case["results"]):
+                    if ref["found"] < 0:
+                        assert not gu[qi]
+                        continue
+                    assert int(gf[qi]) == ref["found"], g["queries"][qi]
+                    assert [int(b) for b in gh[qi, : gn[qi]]["score"].view(np.uint32)] == [h[2] for h in ref["hits"]], g["queries"][qi]
+            # one at a time == batched (the batch shares two device calls), JSON surface intact
+            one = eng.search_batch(g["queries"][:1], 10)
+            many = eng.search_batch(g["queries"], 10)
+            assert one[0].tobytes() == many[0][:1].tobytes()
+            assert '"results"' in eng.search_json(g["queries"][0], 5)
+        finally:
+            eng.close()
+    finally:
+        os.remove(path)

@@ -156,7 +156,60 @@ def make_invert_fixture(outdir):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+SEM_FIXTURE = dict(n_segments=2, docs_per_segment=2500, vocab=1536, seed=23, legacy=False, emb_dim=24, emb_seed=5)
+
+
+def sem_queries(vocab):
+    rng = random.Random(99)
+    qs = ["covid vaccine", "covid covid", "virus", "the of a", "", "zzzz nothing here", "COVID-19 Vaccine!"]
+    for _ in range(25):
+        n = rng.choice([1, 2, 2, 3, 4])
+        qs.append(" ".join(workloads.term_name(rng.randint(1, vocab)) for _ in range(n)))
+    qs.append(workloads.term_name(40) + " " + workloads.term_name(40) + " zz_notindexed_5")
+    return qs
+
+
+def make_sem_fixture(outdir):
+    """Semantic expansion: what the REAL reference does with an embeddings file next to the index —
+    the loaded table's shape, the weighted terms Engine::search scores (order and weight bits), and the hits."""
+    import subprocess
+    p = SEM_FIXTURE
+    tmp = tempfile.mkdtemp(prefix="ns_golden_sem_")
+    try:
+        idx = os.path.join(tmp, "index")
+        nsbind.gen_index(idx, p["n_segments"], p["docs_per_segment"], p["vocab"], p["seed"], p["legacy"])
+        emb = workloads.embeddings_text(p["vocab"], p["emb_dim"], p["emb_seed"])
+        with open(os.path.join(idx, "embeddings.vec"), "wb") as f:
+            f.write(emb)
+        queries = sem_queries(p["vocab"])
+        qpath, opath = os.path.join(tmp, "q.txt"), os.path.join(tmp, "e.txt")
+        with open(qpath, "w") as f:
+            f.write("\n".join(queries) + "\n")
+        subprocess.check_call([orc.REF_DRIVER, "expand", idx, qpath, "10", opath], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        lines = open(opath).read().split("\n")
+        _, enabled, rows, dim = lines[0].split()
+        pos, expands = 1, []
+        for _ in queries:
+            n = int(lines[pos].split()[1])
+            expands.append([[ln.split("\t")[0], int(ln.split("\t")[1], 16)] for ln in lines[pos + 1: pos + 1 + n]])
+            pos += 1 + n
+        cases = []
+        for k in (10, 100):
+            cases.append({"k": k, "results": orc.run_ref_driver(idx, queries, k, tmp)})
+        with open(os.path.join(outdir, "sem1.json"), "w") as f:
+            json.dump({"name": "sem1", "params": p, "embeddings_sha256": hashlib.sha256(emb).hexdigest(), "table": {"enabled": int(enabled), "rows": int(rows), "dim": int(dim)},
+                       "queries": queries, "expand": expands, "cases": cases,
+                       "source": "cord19::Engine (reload + sem.expand + search) of /root/reference with embeddings.vec in the index directory, via oracle/_ref/ref_driver expand|search"},
+                      f, separators=(",", ":"))
+        print("sem1 bytes", os.path.getsize(os.path.join(outdir, "sem1.json")))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "sem":
+        make_sem_fixture(os.path.join(ROOT, "tests", "golden"))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "invert":
         make_invert_fixture(os.path.join(ROOT, "tests", "golden"))
         return
