@@ -53,10 +53,21 @@ __global__ void __launch_bounds__(256) k_sem_sims(const float* __restrict__ vt, 
     float acc[kSemB];
 #pragma unroll
     for (int b = 0; b < kSemB; b++) acc[b] = 0.0f;
-    for (uint32_t i = 0; i < dim; i++) {
+    constexpr uint32_t U = 8;   // table loads in flight per lane (the accumulation below stays in index order)
+    uint32_t i = 0;
+    for (; i + U <= dim; i += U) {
+        float v[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) v[u] = vt[(size_t)(i + u) * rows_pad + r];
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++)
+#pragma unroll
+            for (int b = 0; b < kSemB; b++) acc[b] = acc[b] + q[(size_t)b * dim + i + u] * v[u];   // :13 `s += a[i] * b[i]`
+    }
+    for (; i < dim; i++) {
         const float v = vt[(size_t)i * rows_pad + r];
 #pragma unroll
-        for (int b = 0; b < kSemB; b++) acc[b] = acc[b] + q[(size_t)b * dim + i] * v;   // :13 `s += a[i] * b[i]`
+        for (int b = 0; b < kSemB; b++) acc[b] = acc[b] + q[(size_t)b * dim + i] * v;
     }
 #pragma unroll
     for (int b = 0; b < kSemB; b++) sims[(size_t)b * rows_pad + r] = acc[b];
