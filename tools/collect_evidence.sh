@@ -29,4 +29,8 @@ cd $R
 timeout -k 10 400 python3 tools/law_bench.py > $O/law_bench.txt 2>&1 || exit 1
 timeout -k 10 300 python3 tools/law_bench.py --impacts --laws cfg5,cfg5_thin,cfg5_tile,cfg5_gen,cfg3,cfg3_k10,cfg5_q1,cfg5_q64,cfg5_q1024 >> $O/law_bench.txt 2>&1 || exit 1
 timeout -k 10 300 python3 tools/e2e_bench.py > $O/e2e.txt 2>&1 || exit 1
+# the widening steps' own benches
+timeout -k 10 300 python3 tools/invert_bench.py > $O/invert_bench.json 2> $O/invert_bench.err || exit 1
+timeout -k 10 300 python3 tools/invert_bench.py --docs 1000000 --no-cpu > $O/invert_bench_1m.json 2>> $O/invert_bench.err || exit 1
+timeout -k 10 300 python3 tools/sem_bench.py > $O/sem_bench.json 2> $O/sem_bench.err || exit 1
 echo collected

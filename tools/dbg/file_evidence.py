@@ -31,3 +31,11 @@ cyc=m['SQ_BUSY_CYCLES']/32; cap=cyc/4*1024
 print(f"VALU {m['SQ_INSTS_VALU']:.4g} SALU {m['SQ_INSTS_SALU']:.4g} LDS {m['SQ_INSTS_LDS']:.3g} VALUutil {m['SQ_ACTIVE_INST_VALU']/cap:.2f} SALUutil {m['SQ_INSTS_SALU']/cap:.2f} waves avg {m['SQ_WAVE_CYCLES']*4/cyc:.0f} wait_any {m['SQ_WAIT_ANY']/m['SQ_WAVE_CYCLES']:.2f} wait_inst {m['SQ_WAIT_INST_ANY']/m['SQ_WAVE_CYCLES']:.2f}")
 open(f'{P}/final_cfg5_pmc_sq.csv','w').write("counter,mean_per_dispatch\n"+"\n".join(f"{k},{v:.6g}" for k,v in m.items())+"\n")
 print(open(f'{P}/final_cfg5_kernel_stats.csv').readlines()[1][:40], open(f'{P}/final_cfg5_kernel_stats.csv').readlines()[1].split('",')[-1][:60])
+
+for a, b in (('invert_bench.json', 'final_invert_bench.json'), ('invert_bench_1m.json', 'final_invert_bench_1m.json'), ('sem_bench.json', 'final_sem_bench.json')):
+    import os
+    if os.path.exists(f'{O}/{a}') and os.path.getsize(f'{O}/{a}') > 10:
+        shutil.copy(f'{O}/{a}', f'{P}/{b}')
+        j = json.loads(open(f'{O}/{a}').read().strip().split('\n')[-1])
+        print(a, 'value', round(j['value']), 'device_ms', round(j['device_ms'], 3), 'frac', round(j['roofline']['frac'], 4))
+shutil.copy(f'{O}/tests.txt', f'{P}/final_gpu_tests.txt')
