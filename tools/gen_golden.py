@@ -206,7 +206,58 @@ def make_sem_fixture(outdir):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def segwriter_spec(n_docs=150, seed=31):
+    """Logical documents for the reference's SegmentWriter: cord_uid, title, json_relpath, doc_len, term:tf ..."""
+    rng = random.Random(seed)
+    vocab = ["covid", "virus", "vaccine", "protein", "cell"] + [workloads.term_name(r) for r in range(9, 400)]
+    lines = []
+    for d in range(n_docs):
+        n = rng.choice([0, 1, 3, 8, 15, 30]) if d % 17 else 0          # some documents hold no terms
+        terms = rng.sample(vocab, min(n, len(vocab)))
+        tfs = ["%s:%d" % (t, 1 + int(rng.expovariate(0.7))) for t in terms]
+        doc_len = sum(int(x.split(":")[1]) for x in tfs) + rng.randint(0, 40)
+        lines.append("uid%05d\tTitle of %d\tdocs/%d.json\t%d\t%s" % (d, d, d, doc_len, " ".join(tfs)))
+    return "\n".join(lines) + "\n"
+
+
+def make_segwriter_fixture(outdir):
+    """Tier T0: files written by the REFERENCE's own SegmentWriter (include/segment_writer.hpp) for a
+    committed logical input — what this repo's loader must read and its inversion step must reproduce."""
+    import base64
+    import subprocess
+    tool = os.path.join(ROOT, "oracle", "_ref", "ref_segwriter")
+    if not os.path.exists(tool):
+        sys.exit("oracle/_ref/ref_segwriter missing: run `make -C oracle ref` where /root/reference is mounted")
+    tmp = tempfile.mkdtemp(prefix="ns_golden_sw_")
+    try:
+        spec = segwriter_spec()
+        sp = os.path.join(tmp, "spec.tsv")
+        with open(sp, "w") as f:
+            f.write(spec)
+        idx = os.path.join(tmp, "index")
+        os.makedirs(idx)
+        subprocess.run([tool, sp, idx], check=True)
+        seg = os.path.join(idx, "segments", "seg_000000")
+        files = {}
+        for name in sorted(os.listdir(seg)):
+            b = open(os.path.join(seg, name), "rb").read()
+            files[name] = {"bytes": len(b), "sha256": hashlib.sha256(b).hexdigest()}
+        keep = {n: base64.b64encode(open(os.path.join(seg, n), "rb").read()).decode() for n in ("stats.bin", "docs.bin", "forward.bin", "terms.bin")}
+        queries = ["covid", "virus vaccine", "protein cell covid", workloads.term_name(20) + " " + workloads.term_name(77), "nothinghere"]
+        cases = [{"k": 10, "results": orc.run_ref_driver(idx, queries, 10, tmp)}]
+        with open(os.path.join(outdir, "segwriter1.json"), "w") as f:
+            json.dump({"what": "SegmentWriter::write_segment of /root/reference (include/segment_writer.hpp) on `spec`, via oracle/_ref/ref_segwriter; "
+                               "`results`: the reference engine's search over that index (oracle/_ref/ref_driver)",
+                       "spec": spec, "files": files, "inputs_base64": keep, "queries": queries, "cases": cases}, f, indent=0)
+        print("segwriter1 bytes", os.path.getsize(os.path.join(outdir, "segwriter1.json")))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "segwriter":
+        make_segwriter_fixture(os.path.join(ROOT, "tests", "golden"))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "sem":
         make_sem_fixture(os.path.join(ROOT, "tests", "golden"))
         return
