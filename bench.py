@@ -41,6 +41,8 @@ def parse_args():
     ap.add_argument("--split", type=int, default=0, help="postings per work item (0 = library default)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--index-dir", default="", help="reuse/generate the index here instead of a temp dir")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL over xGMI; the measured configuration) or gloo (rehearsal of the N > 1 code path with several ranks on ONE GPU)")
     ap.add_argument("--no-impact-leg", action="store_true", help="skip the extra measurement over the optional impact streams (profiling runs)")
     return ap.parse_args()
 
@@ -89,12 +91,17 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (there is no CPU path); torch.cuda.is_available() is False")
+    if args.backend == "gloo":   # rehearsal: ranks share the devices that exist
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dist = None
     if n_gpus > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
 
     gen, q_default, K, flags, (nseg, docs) = workloads.WORKLOADS[args.config]
     Q = args.queries or q_default
