@@ -37,6 +37,12 @@ int nsh_invert_segment(const char* seg_dir, int device, uint64_t* pairs, uint64_
                        double* call_s, double* total_s);
 const char* nsh_invert_error(void);
 
+/* Search-result cache around nsh_engine_search_json (src/api_engine.cpp:190-250,:380-385,:539): "query|K" keys,
+ * 2600 entries, LRU eviction, hits carry "from_cache": true.  On by default, in memory only; the batch entry
+ * points never use it. */
+void nsh_engine_set_cache(nsh_engine* e, int on);
+uint32_t nsh_engine_cache_size(nsh_engine* e);
+
 /* Semantic query expansion (src/api_engine.cpp:115-153,:409-417; src/semantic_embedding.cpp): reload() loads
  * <index>/embeddings.vec|embeddings.txt|glove.txt|vectors.txt (or $EMBEDDINGS_PATH) for the lexicons' terms and
  * uploads the table; every search then scores the expanded, weighted terms (similarity search on the device,

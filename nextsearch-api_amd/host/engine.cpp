@@ -35,6 +35,8 @@ void Engine::release_device_segments() {
 
 bool Engine::reload() {
     err_.clear();
+    cache_.clear();
+    lru_.clear();
     // manifest, else scan segments/seg_* sorted (src/api_engine.cpp:57-73)
     std::vector<std::string> names = nsx::load_manifest(index_dir / "manifest.bin");
     if (names.empty()) {
@@ -318,16 +320,46 @@ bool Engine::search_batch_json(const std::vector<std::string>& queries, int k, s
     return true;
 }
 
-std::string Engine::search(const std::string& query, int k) {
+bool Engine::search_text(const std::string& query, int k, std::string& body) {
+    const int K = std::max(1, std::min(k, 100));
+    const std::string key = query + "|" + std::to_string(K);            // make_cache_key (:190-192), K already clamped (:377-380)
+    if (cache_on_) {
+        auto it = cache_.find(key);
+        if (it != cache_.end()) {                                       // get_from_cache (:195-210)
+            lru_.erase(it->second.lru);
+            lru_.push_front(key);
+            it->second.lru = lru_.begin();
+            // result["from_cache"] = true: nlohmann keeps keys sorted, so the flag sits right before "k"
+            body = it->second.body;
+            const size_t at = body.find("  \"k\": ");
+            if (at != std::string::npos) body.insert(at, "  \"from_cache\": true,\n");
+            return true;
+        }
+    }
     SearchResult r;
-    if (!search_hits(query, k, NS_FLAG_OR, r)) {
+    if (!search_hits(query, k, NS_FLAG_OR, r)) return false;
+    body = to_json(r);
+    if (cache_on_ && r.has_found) {                                     // put_in_cache (:213-250); the early returns (:407,:424) skip it
+        if (cache_.size() >= kMaxCacheSize) {
+            auto ev = cache_.find(lru_.back());
+            if (ev != cache_.end()) { lru_.erase(ev->second.lru); cache_.erase(ev); }
+        }
+        lru_.push_front(key);
+        cache_[key] = CacheEntry{body, lru_.begin()};
+    }
+    return true;
+}
+
+std::string Engine::search(const std::string& query, int k) {
+    std::string body;
+    if (!search_text(query, k, body)) {
         // the reference lets exceptions reach the HTTP layer's 500 handler (src/api_server.cpp:76-84)
         std::string o = "{\n  \"error\": ";
         json_escape(o, err_);
         o += "\n}";
         return o;
     }
-    return to_json(r);
+    return body;
 }
 
 }  // namespace nextsearch

@@ -15,6 +15,7 @@
 #pragma once
 
 #include <cstdint>
+#include <list>
 #include <string>
 #include <vector>
 
@@ -63,6 +64,13 @@ public:
     bool build_impacts();
     void use_impacts(bool on);
     std::string search(const std::string& query, int k);        // include/api_engine.hpp:66 (JSON text, dump(2) layout)
+    // Search-result cache around search() (src/api_engine.cpp:190-250,:380-385,:539): key "query|K", at most 2600
+    // entries, least recently used evicted, a hit returns the stored body plus "from_cache": true.  In memory only:
+    // the reference also rewrites search_cache.json in the CWD on every insert (:245-249), which is not reproduced.
+    bool search_text(const std::string& query, int k, std::string& body);   // search() with the failure visible to the caller
+    void set_cache(bool on) { cache_on_ = on; if (!on) { cache_.clear(); lru_.clear(); } }
+    size_t cache_size() const { return cache_.size(); }
+    static constexpr size_t kMaxCacheSize = 2600;               // include/api_engine.hpp:42
     bool search_hits(const std::string& query, int k, uint32_t flags, SearchResult& out);
     bool search_batch(const std::vector<std::string>& queries, int k, uint32_t flags, std::vector<SearchResult>& out);
 
@@ -87,6 +95,10 @@ public:
 
 private:
     void release_device_segments();
+    struct CacheEntry { std::string body; std::list<std::string>::iterator lru; };
+    std::unordered_map<std::string, CacheEntry> cache_;
+    std::list<std::string> lru_;   // most recently used at the front
+    bool cache_on_ = true;
     mutable bool refs_failed_ = false;   // build_refs could not run the device part of the expansion (err_ says why)
     int device_;
     ns_ctx* ctx_ = nullptr;

@@ -162,9 +162,8 @@ extern "C" int nsh_engine_build_refs(nsh_engine* e, const char* const* queries, 
 
 extern "C" int nsh_engine_search_json(nsh_engine* e, const char* query, int k, char** json_out) {
     if (!e || !json_out) return -1;
-    nextsearch::SearchResult r;
-    bool ok = e->eng.search_hits(query ? query : "", k, NS_FLAG_OR, r);
-    std::string s = ok ? e->eng.to_json(r) : std::string();
+    std::string s;
+    const bool ok = e->eng.search_text(query ? query : "", k, s);   // Engine::search: the result cache included
     if (!ok) { e->err = e->eng.last_error(); *json_out = nullptr; return -1; }
     *json_out = (char*)std::malloc(s.size() + 1);
     std::memcpy(*json_out, s.c_str(), s.size() + 1);
@@ -262,6 +261,10 @@ extern "C" int nsh_engine_expand(nsh_engine* e, const char* query, char** text_o
     std::memcpy(*text_out, o.c_str(), o.size() + 1);
     return 0;
 }
+
+// Search-result cache of Engine::search (src/api_engine.cpp:190-250): on by default as in the reference.
+extern "C" void nsh_engine_set_cache(nsh_engine* e, int on) { if (e) e->eng.set_cache(on != 0); }
+extern "C" uint32_t nsh_engine_cache_size(nsh_engine* e) { return e ? (uint32_t)e->eng.cache_size() : 0; }
 
 extern "C" int nsh_engine_build_impacts(nsh_engine* e) {
     if (!e) return -1;

@@ -64,7 +64,7 @@ HOST_SYMBOLS = [
     "nsh_base_terms", "nsh_engine_build_refs", "nsh_engine_search_json", "nsh_free",
     "nsh_engine_search_batch", "nsh_engine_prepare", "nsh_engine_doc_metadata", "nsh_engine_hits_to_json", "nsh_engine_search_batch_json",
     "nsh_engine_build_impacts", "nsh_engine_use_impacts", "nsh_invert_segment", "nsh_invert_error",
-    "nsh_engine_semantic_info", "nsh_engine_expand",
+    "nsh_engine_semantic_info", "nsh_engine_expand", "nsh_engine_set_cache", "nsh_engine_cache_size",
 ]
 
 _hip = None
@@ -153,6 +153,10 @@ def host_lib():
         L.nsh_engine_search_batch_json.argtypes = [vp, C.POINTER(C.c_char_p), u32, i32, C.POINTER(vp), vp]
         L.nsh_invert_segment.argtypes = [C.c_char_p, i32, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.nsh_invert_error.restype = C.c_char_p
+        L.nsh_engine_set_cache.argtypes = [vp, i32]
+        L.nsh_engine_set_cache.restype = None
+        L.nsh_engine_cache_size.argtypes = [vp]
+        L.nsh_engine_cache_size.restype = u32
         L.nsh_engine_semantic_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
         L.nsh_engine_expand.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
         L.nsh_engine_build_impacts.argtypes = [vp]
@@ -365,6 +369,12 @@ class Engine:
         if rc != 0:
             raise RuntimeError(f"prepare failed: {self.error()}")
         return Batch(b, len(queries), clamp_k(k))
+
+    def set_cache(self, on):
+        self._L.nsh_engine_set_cache(self.h, 1 if on else 0)
+
+    def cache_size(self):
+        return self._L.nsh_engine_cache_size(self.h)
 
     def semantic_info(self):
         rows, dim = C.c_uint32(), C.c_uint32()

@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
     std::string qpath = fs::absolute(argv[3]).string();
     int K = std::atoi(argv[4]);
     std::string last = argv[5];
-    std::string outpath = (mode == "search" || mode == "json" || mode == "expand") ? fs::absolute(last).string() : std::string();
+    std::string outpath = (mode == "search" || mode == "json" || mode == "json2" || mode == "expand") ? fs::absolute(last).string() : std::string();
 
     auto queries = read_lines(qpath);
 
@@ -111,6 +111,21 @@ int main(int argc, char** argv) {
                 std::fputc('\n', out);
             }
             std::fclose(out);
+        } else if (mode == "json2") {
+            // the search-result cache (src/api_engine.cpp:190-250): the SECOND answer to each query, cache kept
+            std::FILE* out = std::fopen(outpath.c_str(), "w");
+            if (!out) { std::perror("out"); return 1; }
+            for (auto& q : queries) {
+                (void)engine.search(q, K);
+                json j = engine.search(q, K);
+                const std::string text = j.dump(2);
+                std::fprintf(out, "J %zu\n", text.size());
+                std::fwrite(text.data(), 1, text.size(), out);
+                std::fputc('\n', out);
+            }
+            std::fprintf(out, "C %zu\n", engine.cache.size());
+            std::fclose(out);
+            drop_cache(engine);
         } else if (mode == "expand") {
             // the weighted terms Engine::search scores (src/api_engine.cpp:386-417), in scoring order
             std::FILE* out = std::fopen(outpath.c_str(), "w");

@@ -4,6 +4,7 @@ path against the CPU oracle: docIds, ranks, `found` and fp32 score BITS must be 
 (north_star allows 1e-4 on scores; we hold bit-exact and assert it).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -146,6 +147,7 @@ def test_search_json_with_metadata_equals_reference_text(tmp_path_factory):
     g, d, _ = _meta_index(tmp_path_factory)
     eng = nsbind.Engine(d, 0)
     exact = 0
+    eng.set_cache(False)   # the golden texts are first answers (ref_driver empties the result cache per call)
     for case in g["cases"]:
         for q, text in zip(g["queries"], case["json"]):
             j = json.loads(text)
@@ -170,6 +172,40 @@ def test_search_json_with_metadata_equals_reference_text(tmp_path_factory):
         assert body == eng.search_json(q, 5)
     assert bodies[len(g["queries"]):2 * len(g["queries"])] == bodies[: len(g["queries"])]
     eng.close()
+
+
+def test_search_cache_equals_reference_second_answers(index_factory):
+    """Search-result cache around Engine::search (src/api_engine.cpp:190-250,:380-385,:539): the second answer to a
+    query carries "from_cache": true, early returns are not cached, keys are "query|K"; then LRU eviction at 2600."""
+    import json as _json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "cache1.json")) as f:
+        g = _json.load(f)
+    p = g["params"]
+    d, _ = index_factory(p["n_segments"], p["docs_per_segment"], p["vocab"], p["seed"], p["legacy"])
+    eng = nsbind.Engine(d, 0)
+    try:
+        for q, want in zip(g["queries"], g["second_answers"]):
+            eng.search_json(q, g["k"])
+            assert eng.search_json(q, g["k"]) == want, q
+        assert eng.cache_size() == g["cache_entries"]
+        assert '"from_cache"' not in eng.search_json(g["queries"][0], g["k"] + 1)      # another K, another key
+        assert '"from_cache"' not in eng.search_json(g["queries"][0], 250)             # K is clamped to 100 before the key is made
+        assert '"from_cache": true' in eng.search_json(g["queries"][0], 100)
+        # eviction: 2600 entries, the least recently used one goes
+        eng.set_cache(False); eng.set_cache(True)
+        qs = [workloads.term_name(r) for r in range(9, 9 + 2601)]
+        for q in qs[:2600]:
+            eng.search_json(q, 1)
+        assert eng.cache_size() == 2600
+        assert '"from_cache": true' in eng.search_json(qs[0], 1)       # refreshes qs[0]; qs[1] is now the oldest
+        eng.search_json(qs[2600], 1)                                     # evicts qs[1]
+        assert eng.cache_size() == 2600
+        assert '"from_cache"' not in eng.search_json(qs[1], 1)
+        assert '"from_cache": true' in eng.search_json(qs[0], 1)
+        eng.set_cache(False)
+        assert '"from_cache"' not in eng.search_json(qs[0], 1) and eng.cache_size() == 0
+    finally:
+        eng.close()
 
 
 def test_raw_abi_weights_and_errors(engines):

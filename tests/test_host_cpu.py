@@ -301,3 +301,25 @@ def test_generator_shapes():
         assert eng.lookup(0, "t004097") is None
         assert abs(total - 0.6 * n * sum(1.0 / r for r in range(1, 4097))) < 0.03 * total
         eng.close()
+
+
+def test_search_cache_holds_only_answers():
+    """Search-result cache (src/api_engine.cpp:195-250), host side only: the engine below has no device, so every
+    miss fails before it could insert; the cache must stay empty and switch off/on cleanly.  (Hits, `from_cache`,
+    what is and is not cached, and LRU eviction are pinned on the GPU, tests/test_gpu_parity.py, against the
+    reference's own second answers in tests/golden/cache1.json.)"""
+    import tempfile
+    d = tempfile.mkdtemp(prefix="ns_cache_")
+    idx = os.path.join(d, "i")
+    nsbind.gen_index(idx, 1, 200, 64, 3, False)
+    eng = nsbind.Engine(idx, -1)
+    try:
+        assert eng.cache_size() == 0
+        with pytest.raises(RuntimeError):                     # no device: the search fails and nothing is cached
+            eng.search_json("covid", 5)
+        assert eng.cache_size() == 0
+        eng.set_cache(False)
+        eng.set_cache(True)
+        assert eng.cache_size() == 0
+    finally:
+        eng.close()

@@ -8,6 +8,7 @@ import nsbind, workloads
 tmp = tempfile.TemporaryDirectory(); idx = os.path.join(tmp.name, "i")
 nsbind.gen_index(idx, 1, 1_000_000, 65536, 1337, False)
 eng = nsbind.Engine(idx, 0)
+eng.set_cache(False)
 qs = workloads.cfg5_queries()[:200]
 for rep in range(3):
     acc = [0.0] * 4

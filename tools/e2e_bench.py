@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.join(ROOT, "nextsearch-api_amd"))
 import nsbind, workloads
 tmp = tempfile.TemporaryDirectory(); idx = os.path.join(tmp.name, "i")
 nsbind.gen_index(idx, 1, 1_000_000, 65536, 1337, False)
-t0 = time.perf_counter(); eng = nsbind.Engine(idx, 0); t1 = time.perf_counter()
+t0 = time.perf_counter(); eng = nsbind.Engine(idx, 0); t1 = time.perf_counter(); eng.set_cache(False)   # time searches, not the result cache (src/api_engine.cpp:380-385)
 print(f"Engine.reload (load 83 MB index from disk + upload + norms): {t1 - t0:.3f} s")
 qs = workloads.cfg5_queries(); Q = len(qs)
 eng.search_batch(qs[:64], 10)
@@ -25,7 +25,7 @@ import workloads as _w  # noqa: E402
 with open(os.path.join(idx, "metadata.csv"), "wb") as f:
     f.write(_w.metadata_csv(1_000_000, 11))
 eng.close()
-t0 = time.perf_counter(); eng = nsbind.Engine(idx, 0); t1 = time.perf_counter()
+t0 = time.perf_counter(); eng = nsbind.Engine(idx, 0); t1 = time.perf_counter(); eng.set_cache(False)   # time searches, not the result cache (src/api_engine.cpp:380-385)
 print(f"Engine.reload with a {os.path.getsize(os.path.join(idx, 'metadata.csv')) >> 20} MB metadata.csv: {t1 - t0:.3f} s")
 for what in ("first 500 requests after reload (one-time costs: kernel code load, pinned staging, block pool)", "steady state"):
     t0 = time.perf_counter()

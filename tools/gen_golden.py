@@ -254,7 +254,39 @@ def make_segwriter_fixture(outdir):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def make_cache_fixture(outdir):
+    """Search-result cache (src/api_engine.cpp:190-250): the reference's SECOND answer to each query (cache kept)."""
+    import subprocess
+    p = FIXTURES["small2"]
+    tmp = tempfile.mkdtemp(prefix="ns_golden_cache_")
+    try:
+        idx = os.path.join(tmp, "index")
+        nsbind.gen_index(idx, p["n_segments"], p["docs_per_segment"], p["vocab"], p["seed"], p["legacy"])
+        queries = ["covid", "covid vaccine", "the of", "zzzzunknown", "covid"]
+        qpath, opath = os.path.join(tmp, "q.txt"), os.path.join(tmp, "o.txt")
+        with open(qpath, "w") as f:
+            f.write("\n".join(queries) + "\n")
+        subprocess.check_call([orc.REF_DRIVER, "json2", idx, qpath, "5", opath], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        data = open(opath, "rb").read()
+        out, pos = [], 0
+        while data[pos:pos + 2] == b"J ":
+            nl = data.index(b"\n", pos)
+            n = int(data[pos + 2:nl])
+            out.append(data[nl + 1:nl + 1 + n].decode("utf-8"))
+            pos = nl + 1 + n + 1
+        entries = int(data[pos + 2:data.index(b"\n", pos)])
+        with open(os.path.join(outdir, "cache1.json"), "w") as f:
+            json.dump({"name": "cache1", "params": p, "k": 5, "queries": queries, "second_answers": out, "cache_entries": entries,
+                       "source": "cord19::Engine::search called twice per query, second dump(2), via oracle/_ref/ref_driver json2"}, f, separators=(",", ":"))
+        print("cache1 bytes", os.path.getsize(os.path.join(outdir, "cache1.json")), "entries", entries)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "cache":
+        make_cache_fixture(os.path.join(ROOT, "tests", "golden"))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "segwriter":
         make_segwriter_fixture(os.path.join(ROOT, "tests", "golden"))
         return
