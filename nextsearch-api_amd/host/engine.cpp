@@ -82,6 +82,22 @@ bool Engine::reload() {
     segments = std::move(loaded);
     // metadata mapping (src/api_engine.cpp:110-113): absent file = no decoration, not an error
     meta.load(index_dir / "metadata.csv", segments);
+    // warm-up: the first requests after a reload otherwise pay for loading the kernels' code objects and for the
+    // pinned staging buffers (~60 ms spread over the first few hundred requests).  One lone query over the longest
+    // list of the first segment takes the same route (k_pull, k_uscore, k_merge_wide) once, here.
+    if (ctx_ && !segments.empty()) {
+        const nsx::LexEntry* best = nullptr;
+        for (const auto& kv : segments[0].lex)
+            if (kv.second.df && (!best || kv.second.count > best->count)) best = &kv.second;
+        if (best) {
+            ns_term_ref r;
+            r.seg_id = 0; r.count = best->count; r.byte_off = segments[0].list_byte_offset(*best);
+            r.idf = bm25_idf(segments[0].N, best->df); r.qweight = 1.0f;
+            ns_query_desc qd{0, 1};
+            ns_hit hits[10]; uint32_t nh = 0; uint64_t fd = 0;
+            (void)ns_search_batch(ctx_, &qd, &r, 1, 10, hits, &nh, &fd, NS_FLAG_OR);
+        }
+    }
     // embeddings (src/api_engine.cpp:115-153): only the terms some lexicon holds; absent or unusable file = no expansion
     sem.clear();
     {
