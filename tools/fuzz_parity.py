@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Randomised differential test of the HIP path against the CPU oracle (test infrastructure; GPU box only):
+random index shapes, query laws, K, OR/AND, work-splitting knobs, with and without impact streams.
+Stops at the first mismatch and prints the case; prints a summary line otherwise."""
+import argparse
+import os
+import random
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "nextsearch-api_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import nsbind  # noqa: E402
+import orc  # noqa: E402
+import workloads  # noqa: E402
+
+
+def same(gpu, ora):
+    gh, gn, gf, gu = gpu
+    oh, on, of, ou = ora
+    if not np.array_equal(gu.astype(bool), ou.astype(bool)):
+        return "usable"
+    for q in range(len(on)):
+        if not ou[q]:
+            continue
+        if int(gf[q]) != int(of[q]):
+            return f"found q{q}: {gf[q]} vs {of[q]}"
+        if int(gn[q]) != int(on[q]):
+            return f"nhits q{q}"
+        n = int(on[q])
+        g, o = gh[q, :n], oh[q, :n]
+        if not (np.array_equal(g["doc"], o["doc"]) and np.array_equal(g["seg"], o["seg"]) and np.array_equal(g["score"].view(np.uint32), o["score"].view(np.uint32))):
+            return f"hits q{q}"
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=240.0)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    rng = random.Random(args.seed)
+    t0 = time.time()
+    cases = 0
+    tmp = tempfile.mkdtemp(prefix="ns_fuzz_")
+    while time.time() - t0 < args.seconds:
+        nseg = rng.choice([1, 1, 2, 3, 5])
+        docs = rng.choice([300, 2000, 9000, 40000, 120000])
+        vocab = rng.choice([64, 512, 4096, 16384])
+        seed = rng.randint(1, 10**6)
+        idx = os.path.join(tmp, f"i{cases}")
+        nsbind.gen_index(idx, nseg, docs, vocab, seed, rng.random() < 0.15 and nseg == 1)
+        eng, ora = nsbind.Engine(idx, 0), orc.Oracle(idx)
+        try:
+            for rep in range(4):
+                nq = rng.choice([1, 3, 17, 64, 300])
+                law = rng.choice(["cfg5", "cfg3", "pairs", "dups", "many"])
+                qs = []
+                for _ in range(nq):
+                    if law == "cfg5":
+                        qs.append(workloads.cfg5_queries(1, rng.randint(1, 10**6), vocab)[0])
+                    elif law == "cfg3":
+                        qs.append(" ".join(workloads.term_name(rng.randint(1, min(vocab, 40))) for _ in range(5)))
+                    elif law == "pairs":
+                        qs.append(workloads.term_name(rng.randint(1, min(vocab, 12))) + " " + workloads.term_name(rng.randint(1, vocab)))
+                    elif law == "dups":
+                        t = workloads.term_name(rng.randint(1, min(vocab, 30)))
+                        qs.append(" ".join([t] * rng.randint(2, 4) + [workloads.term_name(rng.randint(1, vocab))]))
+                    else:
+                        qs.append(" ".join(workloads.term_name(rng.randint(1, vocab)) for _ in range(rng.randint(9, 40))))
+                k = rng.choice([1, 3, 10, 33, 64, 100])
+                flags = rng.choice([0, 0, 0, nsbind.NS_FLAG_AND])
+                tune = rng.choice([(0, 0, 0), (0, 0, 0), (0, 4096, 0), (0, 1, 1 << 30), (0, 20000, 700), (0, 1, 300)])
+                eng.set_tuning(*tune)
+                imp = rng.random() < 0.4
+                if imp:
+                    eng.build_impacts()
+                eng.use_impacts(imp)
+                bad = same(eng.search_batch(qs, k, flags), ora.search_batch(qs, k, flags, threads=8))
+                if bad:
+                    print(f"MISMATCH {bad}: index(nseg={nseg}, docs={docs}, vocab={vocab}, seed={seed}) law={law} nq={nq} k={k} flags={flags} tune={tune} impacts={imp}")
+                    print("queries:", qs[:5])
+                    sys.exit(1)
+                cases += 1
+        finally:
+            eng.close()
+            ora.close()
+    print(f"fuzz: {cases} batches equal to the oracle in {time.time() - t0:.0f} s (seed {args.seed})")
+
+
+if __name__ == "__main__":
+    main()
