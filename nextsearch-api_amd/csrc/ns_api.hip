@@ -1170,16 +1170,19 @@ extern "C" int ns_invert_forward(ns_ctx* ctx, const uint32_t* doc_term_counts, u
             hipLaunchKernelGGL(k_iv_scatter, dim3(n_tiles), dim3(256), 0, st, d_keys[cur], d_vals[cur], d_keys[cur ^ 1], d_vals[cur ^ 1], n, shift, d_hist, n_tiles);
             cur ^= 1;
         }
-        if (n_terms) {
-            hipLaunchKernelGGL(k_iv_run_starts, dim3((n + 255) / 256), dim3(256), 0, st, d_keys[cur], n, n_terms, d_first);
-            hipLaunchKernelGGL(k_iv_run_lengths, dim3((n + 255) / 256), dim3(256), 0, st, d_keys[cur], n, n_terms, d_first, d_df);
+        std::vector<uint32_t> h_first(n_terms);
+        if (n_terms) {   // d_df holds the runs' last positions, 0xFFFFFFFF in d_first marks a term without postings
+            chk(hipMemsetAsync(d_first, 0xFF, (size_t)n_terms * 4, st));
+            hipLaunchKernelGGL(k_iv_runs, dim3((n + 255) / 256), dim3(256), 0, st, d_keys[cur], n, n_terms, d_first, d_df);
         }
         chk(hipEventRecord(ev1, st));
         chk(hipGetLastError());
         if (n_terms) chk(hipMemcpyAsync(df_out, d_df, (size_t)n_terms * 4, hipMemcpyDeviceToHost, st));
+        if (n_terms) chk(hipMemcpyAsync(h_first.data(), d_first, (size_t)n_terms * 4, hipMemcpyDeviceToHost, st));
         chk(hipStreamSynchronize(st));
         if (e == hipSuccess) {
             uint64_t kept = 0;
+            for (uint32_t t = 0; t < n_terms; t++) df_out[t] = (h_first[t] == 0xFFFFFFFFu) ? 0u : df_out[t] - h_first[t] + 1u;
             for (uint32_t t = 0; t < n_terms; t++) kept += df_out[t];
             *kept_out = kept;   // the dropped pairs carry the largest key: they sort behind every list
             if (kept) chk(hipMemcpy(postings_out, d_vals[cur], (size_t)kept * 8, hipMemcpyDeviceToHost));

@@ -13,7 +13,7 @@
 //   per pass:     k_iv_hist (LDS histogram per 4096-pair tile, written digit-major) -> exclusive scan of the
 //                 256 x tiles counters -> k_iv_scatter (stable ranks: wave-level match masks from 8 ballots,
 //                 per-wave digit counters in LDS, waves of a tile ordered by a 256-thread prefix)
-//   k_iv_run_starts / k_iv_run_lengths   df[t] = length of term t's run in the sorted keys
+//   k_iv_runs     first / last position of every term's run in the sorted keys (df = last - first + 1)
 //
 // Integer work only; the result is defined bit for bit (the one freedom the reference leaves — the order of
 // equal docIds inside a list, std::sort being unstable — is resolved as input order).
@@ -95,19 +95,16 @@ __global__ void __launch_bounds__(256) k_iv_expand(const uint2* __restrict__ pai
 }
 
 // df from the SORTED keys (a histogram by atomics serialises on the frequent terms: the most frequent one
-// occurs in almost every document): a run's first pair records where it starts, its last pair the length.
-__global__ void __launch_bounds__(256) k_iv_run_starts(const uint32_t* __restrict__ keys, uint32_t n, uint32_t n_terms, uint32_t* __restrict__ first) {
+// occurs in almost every document): a run's first pair records where it starts, its last pair where it ends;
+// the host subtracts.
+__global__ void __launch_bounds__(256) k_iv_runs(const uint32_t* __restrict__ keys, uint32_t n, uint32_t n_terms,
+                                                 uint32_t* __restrict__ first, uint32_t* __restrict__ last) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint32_t k = keys[i];
-    if (k < n_terms && (i == 0 || keys[i - 1] != k)) first[k] = i;
-}
-__global__ void __launch_bounds__(256) k_iv_run_lengths(const uint32_t* __restrict__ keys, uint32_t n, uint32_t n_terms,
-                                                        const uint32_t* __restrict__ first, uint32_t* __restrict__ df) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t k = keys[i];
-    if (k < n_terms && (i + 1 == n || keys[i + 1] != k)) df[k] = i + 1 - first[k];
+    if (k >= n_terms) return;
+    if (i == 0 || keys[i - 1] != k) first[k] = i;
+    if (i + 1 == n || keys[i + 1] != k) last[k] = i;
 }
 
 __global__ void __launch_bounds__(256) k_iv_hist(const uint32_t* __restrict__ keys, uint32_t n, uint32_t shift,
