@@ -107,16 +107,32 @@ __global__ void __launch_bounds__(256) k_iv_runs(const uint32_t* __restrict__ ke
     if (i + 1 == n || keys[i + 1] != k) last[k] = i;
 }
 
+// Each thread counts 16 CONSECUTIVE keys and issues one LDS atomic per run of equal digits: with 64 lanes adding
+// to the same counter an LDS atomic serialises, and in the upper-byte passes (Zipf-distributed termIds) almost every
+// key of a tile has the same digit.
 __global__ void __launch_bounds__(256) k_iv_hist(const uint32_t* __restrict__ keys, uint32_t n, uint32_t shift,
                                                  uint32_t* __restrict__ tile_hist /* [256][n_tiles] */, uint32_t n_tiles) {
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * (uint32_t)kIvTile;
+    const uint32_t base = blockIdx.x * (uint32_t)kIvTile + threadIdx.x * (uint32_t)kIvItems;
+    if (base + kIvItems <= n) {
+        const uint4* p = reinterpret_cast<const uint4*>(keys + base);   // base is a multiple of 16 keys = 64 B
+        uint32_t k[kIvItems];
 #pragma unroll
-    for (int s = 0; s < kIvItems; s++) {
-        const uint32_t idx = base + (uint32_t)s * 256 + threadIdx.x;
-        if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & 255u], 1u);
+        for (int j = 0; j < kIvItems / 4; j++) {
+            const uint4 v = p[j];
+            k[4 * j] = v.x; k[4 * j + 1] = v.y; k[4 * j + 2] = v.z; k[4 * j + 3] = v.w;
+        }
+        uint32_t d = (k[0] >> shift) & 255u, run = 1;
+#pragma unroll
+        for (int j = 1; j < kIvItems; j++) {
+            const uint32_t dj = (k[j] >> shift) & 255u;
+            if (dj == d) { run++; } else { atomicAdd(&h[d], run); d = dj; run = 1; }
+        }
+        atomicAdd(&h[d], run);
+    } else {
+        for (uint32_t i = base; i < n && i < base + kIvItems; i++) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
     }
     __syncthreads();
     tile_hist[(size_t)threadIdx.x * n_tiles + blockIdx.x] = h[threadIdx.x];
