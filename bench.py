@@ -121,6 +121,7 @@ def main():
         index_dir = os.path.join(tmp.name, "index")
         nsbind.gen_index(index_dir, nseg, docs, 65536, 1337, False)
 
+    os.environ["NS_RELOAD_WARMUP"] = "0"   # no warm-up query at reload: rocprof / PMC summaries of this command then hold the batch launches only
     eng = nsbind.Engine(index_dir, local_rank)
     stream = torch.cuda.current_stream()
     nsbind.hip_lib().ns_ctx_set_stream(eng.ctx, stream.cuda_stream)
@@ -136,6 +137,12 @@ def main():
         gathered = (torch.empty((n_gpus * Q, K, 3), dtype=torch.int32, device="cuda"),
                     torch.empty(n_gpus * Q, dtype=torch.int32, device="cuda"),
                     torch.empty(n_gpus * Q, dtype=torch.int64, device="cuda"))
+
+    # setup, before the contract's W warm-up steps: the first launches after an idle period run ~10 % slow while the
+    # device clocks ramp (3.17, 3.12, 3.04, 2.97, 2.90, then 2.83 ms in profiles/r01/final_cfg5_kernel_trace_head.csv)
+    for _ in range(6):
+        batch.run(timed=False)
+    torch.cuda.synchronize()
 
     def step(timed):
         batch.run(timed=timed)

@@ -85,7 +85,8 @@ bool Engine::reload() {
     // warm-up: the first requests after a reload otherwise pay for loading the kernels' code objects and for the
     // pinned staging buffers (~60 ms spread over the first few hundred requests).  One lone query over the longest
     // list of the first segment takes the same route (k_pull, k_uscore, k_merge_wide) once, here.
-    if (ctx_ && !segments.empty()) {
+    const char* wu = std::getenv("NS_RELOAD_WARMUP");   // "0": skip (bench.py does, so that a profile of it holds the timed launches only)
+    if (ctx_ && !segments.empty() && !(wu && wu[0] == '0')) {
         const nsx::LexEntry* best = nullptr;
         for (const auto& kv : segments[0].lex)
             if (kv.second.df && (!best || kv.second.count > best->count)) best = &kv.second;

@@ -33,4 +33,10 @@ timeout -k 10 300 python3 tools/e2e_bench.py > $O/e2e.txt 2>&1 || exit 1
 timeout -k 10 300 python3 tools/invert_bench.py > $O/invert_bench.json 2> $O/invert_bench.err || exit 1
 timeout -k 10 300 python3 tools/invert_bench.py --docs 1000000 --no-cpu > $O/invert_bench_1m.json 2>> $O/invert_bench.err || exit 1
 timeout -k 10 300 python3 tools/sem_bench.py > $O/sem_bench.json 2> $O/sem_bench.err || exit 1
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/inv_raw -- python3 $R/tools/invert_bench.py --no-cpu > /dev/null 2>&1 || exit 1
+cp $(find $O/inv_raw -name "*kernel_stats.csv" | head -1) $O/invert_kernel_stats.csv; rm -rf $O/inv_raw
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/sem_raw -- python3 $R/tools/sem_bench.py > /dev/null 2>&1 || exit 1
+cp $(find $O/sem_raw -name "*kernel_stats.csv" | head -1) $O/sem_kernel_stats.csv; rm -rf $O/sem_raw
+cd $R
 echo collected

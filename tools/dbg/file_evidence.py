@@ -39,3 +39,9 @@ for a, b in (('invert_bench.json', 'final_invert_bench.json'), ('invert_bench_1m
         j = json.loads(open(f'{O}/{a}').read().strip().split('\n')[-1])
         print(a, 'value', round(j['value']), 'device_ms', round(j['device_ms'], 3), 'frac', round(j['roofline']['frac'], 4))
 shutil.copy(f'{O}/tests.txt', f'{P}/final_gpu_tests.txt')
+
+import re
+for a, b in (('invert_kernel_stats.csv', 'final_invert_kernel_stats.csv'), ('sem_kernel_stats.csv', 'final_sem_kernel_stats.csv')):
+    if os.path.exists(f'{O}/{a}'):
+        open(f'{P}/{b}', 'w').write(re.sub(r'\(.*?\)"', '"', open(f'{O}/{a}').read()))
+        print(open(f'{P}/{b}').read().split('\n')[1][:90])
