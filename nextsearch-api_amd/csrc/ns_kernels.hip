@@ -487,6 +487,49 @@ __global__ void __launch_bounds__(256) k_merge(const DevQuery* __restrict__ quer
     for (uint32_t i = lane; i < pc; i += 64) found += part_found[pb + i];
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) found += __shfl_xor(found, d, 64);
+    if (pc * K <= 64u) {
+        // All entries of all rows fit the wave (the usual case: 1-6 rows at K = 10): one load per lane and one
+        // 64-key bitonic sort on (score desc, (seg, doc) asc) instead of K rounds of dependent head loads.
+        const uint32_t row = (uint32_t)lane / K, idx = (uint32_t)lane - row * K;
+        uint32_t s = 0;            // order_bits(score); 0 == empty lane (sorts last)
+        uint64_t id = ~0ull;
+        if (row < pc && idx < part_nhits[pb + row]) {
+            const Hit e = part_hits[(uint64_t)(pb + row) * K + idx];
+            s = order_bits(e.score);
+            id = ((uint64_t)e.seg << 32) | e.doc;
+        }
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const uint32_t os = (uint32_t)__shfl_xor((int)s, j, 64);
+                const uint64_t oid = __shfl_xor(id, j, 64);
+                const bool other_better = os > s || (os == s && oid < id);
+                const bool lower = (lane & j) == 0;            // this lane keeps the better of the pair in a best-first run
+                const bool best_first = (lane & k) == 0;
+                const bool take = (lower == best_first) ? other_better : !other_better && !(os == s && oid == id);
+                if (take) { s = os; id = oid; }
+            }
+        const uint32_t produced = min((uint32_t)__popcll(__ballot(s != 0u)), K);
+        if ((uint32_t)lane < K) {
+            Hit h;
+            if ((uint32_t)lane < produced) {
+                h.score = unorder_bits(s);
+                h.seg = (uint32_t)(id >> 32);
+                h.doc = (uint32_t)id;
+            } else {
+                h.score = -__builtin_inff();
+                h.seg = 0xFFFFFFFFu;
+                h.doc = 0xFFFFFFFFu;
+            }
+            out_hits[(uint64_t)q * K + lane] = h;
+        }
+        if (lane == 0) {
+            out_nhits[q] = produced;
+            out_found[q] = found;
+        }
+        return;
+    }
     merge_rows_wave(q, pb, pc, part_hits, part_nhits, out_hits, out_nhits, out_found, found, K, heads, lane);
 }
 
