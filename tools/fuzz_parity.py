@@ -45,6 +45,7 @@ def main():
     args = ap.parse_args()
     rng = random.Random(args.seed)
     t0 = time.time()
+    last = t0
     cases = 0
     tmp = tempfile.mkdtemp(prefix="ns_fuzz_")
     while time.time() - t0 < args.seconds:
@@ -86,6 +87,9 @@ def main():
                     print("queries:", qs[:5])
                     sys.exit(1)
                 cases += 1
+                if time.time() - last > 30:
+                    last = time.time()
+                    print(f"... {cases} batches so far ({last - t0:.0f} s)", flush=True)
         finally:
             eng.close()
             ora.close()

@@ -42,6 +42,8 @@ def main():
             print(f"INVERSION MISMATCH docs={n_docs} terms={n_terms} mean={mean}")
             sys.exit(1)
         n_inv += 1
+        if n_inv % 50 == 0:
+            print(f"... {n_inv} inversions ({time.time() - t0:.0f} s)", flush=True)
     L = nsbind.hip_lib()
     ctx = C.c_void_p()
     assert L.ns_ctx_create(0, C.byref(ctx)) == 0
@@ -68,6 +70,8 @@ def main():
                 sys.exit(1)
         L.ns_sem_release(ctx, sem)
         n_sem += 1
+        if n_sem % 500 == 0:
+            print(f"... {n_sem} similarity searches ({time.time() - t0:.0f} s)", flush=True)
     L.ns_ctx_destroy(ctx)
     print(f"fuzz: {n_inv} inversions and {n_sem} similarity searches equal to their oracles in {time.time() - t0:.0f} s")
 
