@@ -323,3 +323,11 @@ def test_search_cache_holds_only_answers():
         assert eng.cache_size() == 0
     finally:
         eng.close()
+
+
+def test_tools_and_entry_points_compile():
+    """bench.py, __graft_entry__.py and every tool parse (they only run on the GPU box)."""
+    import glob
+    import py_compile
+    for f in [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")] + sorted(glob.glob(os.path.join(ROOT, "tools", "**", "*.py"), recursive=True)):
+        py_compile.compile(f, doraise=True)
