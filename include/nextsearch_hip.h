@@ -107,6 +107,17 @@ const char* ns_device_name(ns_ctx* ctx);
 int ns_segment_upload(ns_ctx* ctx, uint32_t seg_id, uint32_t n_docs, float avgdl,
                       const uint32_t* doc_len, const void* postings, uint64_t nbytes, ns_seg** out);
 int ns_segment_release(ns_ctx* ctx, ns_seg* seg);
+/* The same upload for a posting payload that is NOT one host buffer.  The reference keeps a segment's postings in
+ * up to 64 inverted_bNNN.bin files and reads them through open streams (include/api_types.hpp:54-59,
+ * src/api_segment.cpp:70-102); the host maps those files one after the other and appends each mapping, so the
+ * payload never exists in host memory as a whole.  begin: reserves HBM for total_nbytes of postings and takes doc_len;
+ * append: the next nbytes of the payload, in payload order (any multiple of 8; copied through the pinned staging
+ * buffers before the call returns); end: all bytes must have arrived; publishes the segment under seg_id.
+ * ns_segment_release abandons an upload that was begun but not ended. */
+int ns_segment_upload_begin(ns_ctx* ctx, uint32_t seg_id, uint32_t n_docs, float avgdl, const uint32_t* doc_len,
+                            uint64_t total_nbytes, ns_seg** out);
+int ns_segment_upload_append(ns_ctx* ctx, ns_seg* seg, const void* bytes, uint64_t nbytes);
+int ns_segment_upload_end(ns_ctx* ctx, ns_seg* seg);
 
 /* Optional second posting stream of a segment (a format loaded NEXT TO the reference's).
  * For every list given here the device stores {u32 docId, f32 term score} per posting, index-aligned with the

@@ -27,6 +27,10 @@ int nsh_gen_index(const char* index_dir, uint32_t n_segments, uint32_t docs_per_
  * (free it with nsh_engine_close). */
 int  nsh_engine_open(const char* index_dir, int device, nsh_engine** out);
 void nsh_engine_close(nsh_engine* e);
+/* Engine::reload() again on the same directory.  0 on success.  On failure (non-zero) the engine keeps the index,
+ * the device copy and the caches it had (the reference swaps its segments in only after every one loaded,
+ * src/api_engine.cpp:76-90).  On success the device context is a NEW one: re-read nsh_engine_ctx(). */
+int  nsh_engine_reload(nsh_engine* e);
 const char* nsh_engine_error(nsh_engine* e);
 ns_ctx* nsh_engine_ctx(nsh_engine* e);
 
@@ -50,6 +54,8 @@ uint32_t nsh_engine_cache_size(nsh_engine* e);
  * terms of one query, "term<TAB>%08x weight bits" per line in scoring order; free with nsh_free. */
 int nsh_engine_semantic_info(nsh_engine* e, uint32_t* rows, uint32_t* dim);
 int nsh_engine_expand(nsh_engine* e, const char* query, char** text_out);
+/* Row `row` of the loaded table: its term and its `dim` L2-normalised values (valid until close/reload); -1 if absent. */
+int nsh_engine_semantic_row(nsh_engine* e, uint32_t row, const char** term, const float** vec);
 
 /* Optional impact streams for every list of every loaded lexicon (include/nextsearch_hip.h:
  * ns_segment_build_impacts / ns_ctx_use_impacts).  Not part of reload(): 8 B of HBM per posting. */

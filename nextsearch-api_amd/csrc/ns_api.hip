@@ -36,6 +36,15 @@ struct ns_seg {
     float* d_norm = nullptr;    // per doc
     float* d_pnorm = nullptr;   // per posting
     bool norm_safe = false;     // every norm lies in [2^-20, 2^30]: the BM25 division may take its short form (ns_div_short)
+    float avgdl = 0.0f;
+    // upload in progress (ns_segment_upload_begin .. _end): payload bytes received so far, doc_len on the device, pinned staging
+    bool pending = false;
+    uint64_t filled = 0;
+    uint32_t* d_len = nullptr;
+    void* pin[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int stage_k = 0;
+    void* d_packed = nullptr;   // reserved for the packed posting stream (ns_segment_build_packed)
     // Optional impact stream (ns_segment_build_impacts): {docId, term score bits} per posting of the registered lists,
     // index-aligned with d_postings.  `imp_tab`: open-addressed (first posting index -> count, idf bits) of those lists.
     uint2* d_impacts = nullptr;
@@ -84,6 +93,7 @@ struct ns_ctx {
 };
 
 static thread_local std::string g_create_err;
+static void seg_free_device_fwd(ns_seg* s);
 
 static int fail(ns_ctx* ctx, int code, const char* fmt, ...) {
     char buf[512];
@@ -216,10 +226,7 @@ extern "C" void ns_ctx_destroy(ns_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (ns_seg* s : ctx->segs) {
         if (!s) continue;
-        (void)hipFree(s->d_postings);
-        (void)hipFree(s->d_norm);
-        (void)hipFree(s->d_pnorm);
-        (void)hipFree(s->d_impacts);
+        seg_free_device_fwd(s);
         delete s;
     }
     for (auto& blk : ctx->pool) (void)hipFree(blk.p);
@@ -249,14 +256,58 @@ extern "C" int ns_set_tuning(ns_ctx* ctx, uint32_t variant, uint32_t min_items, 
 }
 
 // ------------------------------------------------------------------------------------------------
-extern "C" int ns_segment_upload(ns_ctx* ctx, uint32_t seg_id, uint32_t n_docs, float avgdl, const uint32_t* doc_len,
-                                 const void* postings, uint64_t nbytes, ns_seg** out) {
+// slack behind the payload: the driver stream loads whole rounds of 256 postings (and their norms) from a list's
+// cursor, i.e. up to 255 entries past the end of the last list
+static constexpr size_t kPadPostings = 256;
+static constexpr size_t kStageChunk = 32u << 20;   // pinned, double-buffered: the host memcpy of chunk i+1 overlaps the DMA of chunk i
+
+static void seg_free_staging(ns_seg* s) {
+    for (int i = 0; i < 2; i++) {
+        if (s->pin[i]) (void)hipHostFree(s->pin[i]);
+        if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
+        s->pin[i] = nullptr; s->ev[i] = nullptr;
+    }
+    if (s->d_len) (void)hipFree(s->d_len);
+    s->d_len = nullptr;
+}
+static void seg_free_device(ns_seg* s);
+static void seg_free_device_fwd(ns_seg* s) { seg_free_device(s); }
+static void seg_free_device(ns_seg* s) {
+    (void)hipFree(s->d_postings);
+    (void)hipFree(s->d_norm);
+    (void)hipFree(s->d_pnorm);
+    (void)hipFree(s->d_impacts);
+    (void)hipFree(s->d_packed);
+    s->d_postings = nullptr; s->d_norm = nullptr; s->d_pnorm = nullptr; s->d_impacts = nullptr; s->d_packed = nullptr;
+}
+// host bytes -> device through the segment's two pinned buffers
+static hipError_t seg_stage(ns_ctx* ctx, ns_seg* s, void* dst, const void* src, size_t n) {
+    size_t off = 0;
+    while (off < n) {
+        const size_t c = std::min(kStageChunk, n - off);
+        const int k = s->stage_k;
+        hipError_t r = hipEventSynchronize(s->ev[k]);
+        if (r != hipSuccess) return r;
+        std::memcpy(s->pin[k], (const char*)src + off, c);
+        r = hipMemcpyAsync((char*)dst + off, s->pin[k], c, hipMemcpyHostToDevice, ctx->stream);
+        if (r != hipSuccess) return r;
+        r = hipEventRecord(s->ev[k], ctx->stream);
+        if (r != hipSuccess) return r;
+        off += c;
+        s->stage_k ^= 1;
+    }
+    return hipSuccess;
+}
+
+extern "C" int ns_segment_upload_begin(ns_ctx* ctx, uint32_t seg_id, uint32_t n_docs, float avgdl, const uint32_t* doc_len,
+                                       uint64_t nbytes, ns_seg** out) {
     if (!ctx) return fail(nullptr, NS_E_INVAL, "ns_segment_upload: ctx is NULL");
-    if (out) *out = nullptr;
+    if (!out) return fail(ctx, NS_E_INVAL, "ns_segment_upload_begin: out is NULL");
+    *out = nullptr;
     if (seg_id >= (1u << 20)) return fail(ctx, NS_E_INVAL, "seg_id %u too large", seg_id);
     if (nbytes % 8 != 0) return fail(ctx, NS_E_INVAL, "posting payload of %llu bytes is not a whole number of {u32,u32} pairs", (unsigned long long)nbytes);
     if (nbytes / 8 >= (1ull << 32)) return fail(ctx, NS_E_INVAL, "segment has %llu postings; this build indexes postings with 32 bits (split the segment)", (unsigned long long)(nbytes / 8));
-    if ((n_docs && !doc_len) || (nbytes && !postings)) return fail(ctx, NS_E_INVAL, "null doc_len/postings");
+    if (n_docs && !doc_len) return fail(ctx, NS_E_INVAL, "null doc_len/postings");
     if (seg_id < ctx->segs.size() && ctx->segs[seg_id]) return fail(ctx, NS_E_INVAL, "segment %u already uploaded", seg_id);
     HIPCHK(ctx, hipSetDevice(ctx->device));
 
@@ -265,68 +316,28 @@ extern "C" int ns_segment_upload(ns_ctx* ctx, uint32_t seg_id, uint32_t n_docs, 
     s->id = seg_id;
     s->n_docs = n_docs;
     s->n_postings = nbytes / 8;
-    auto cleanup = [&]() { (void)hipFree(s->d_postings); (void)hipFree(s->d_norm); (void)hipFree(s->d_pnorm); delete s; };
+    s->avgdl = avgdl;
+    s->pending = true;
+    auto cleanup = [&]() { seg_free_staging(s); seg_free_device(s); delete s; };
 
     hipError_t e;
-    uint32_t* d_len = nullptr;
-    // slack: the driver stream loads whole rounds of 256 postings (and their norms) from a list's cursor,
-    // i.e. up to 255 entries past the end of the last list
-    const size_t kPadPostings = 256;
     if ((e = hipMalloc((void**)&s->d_postings, nbytes + kPadPostings * 8)) != hipSuccess) { cleanup(); return fail(ctx, NS_E_NOMEM, "hipMalloc postings (%llu B): %s", (unsigned long long)nbytes, hipGetErrorString(e)); }
     if ((e = hipMalloc((void**)&s->d_norm, (size_t)std::max<uint32_t>(n_docs, 1) * 4)) != hipSuccess) { cleanup(); return fail(ctx, NS_E_NOMEM, "hipMalloc norm: %s", hipGetErrorString(e)); }
     if ((e = hipMalloc((void**)&s->d_pnorm, nbytes / 2 + kPadPostings * 4)) != hipSuccess) { cleanup(); return fail(ctx, NS_E_NOMEM, "hipMalloc per-posting norms (%llu B): %s", (unsigned long long)(nbytes / 2), hipGetErrorString(e)); }
-    if ((e = hipMalloc((void**)&d_len, (size_t)std::max<uint32_t>(n_docs, 1) * 4)) != hipSuccess) { cleanup(); return fail(ctx, NS_E_NOMEM, "hipMalloc doc_len: %s", hipGetErrorString(e)); }
-
-    // pinned, double-buffered staging: host memcpy of chunk i+1 overlaps the DMA of chunk i
-    const size_t kChunk = 32u << 20;
-    void* pin[2] = {nullptr, nullptr};
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    bool ok = true;
-    for (int i = 0; i < 2 && ok; i++) {
-        ok = hipHostMalloc(&pin[i], kChunk, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
-    }
-    auto stage = [&](void* dst, const void* src, size_t n) -> hipError_t {
-        size_t off = 0;
-        int k = 0;
-        while (off < n) {
-            size_t c = std::min(kChunk, n - off);
-            hipError_t r = hipEventSynchronize(ev[k]);
-            if (r != hipSuccess) return r;
-            std::memcpy(pin[k], (const char*)src + off, c);
-            r = hipMemcpyAsync((char*)dst + off, pin[k], c, hipMemcpyHostToDevice, ctx->stream);
-            if (r != hipSuccess) return r;
-            r = hipEventRecord(ev[k], ctx->stream);
-            if (r != hipSuccess) return r;
-            off += c;
-            k ^= 1;
+    if ((e = hipMalloc((void**)&s->d_len, (size_t)std::max<uint32_t>(n_docs, 1) * 4)) != hipSuccess) { cleanup(); return fail(ctx, NS_E_NOMEM, "hipMalloc doc_len: %s", hipGetErrorString(e)); }
+    for (int i = 0; i < 2; i++)
+        if (hipHostMalloc(&s->pin[i], kStageChunk, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&s->ev[i], hipEventDisableTiming) != hipSuccess) {
+            cleanup();
+            return fail(ctx, NS_E_NOMEM, "pinned staging allocation failed");
         }
-        return hipSuccess;
-    };
-    e = hipSuccess;
-    if (ok) {
-        e = hipMemsetAsync((char*)s->d_postings + nbytes, 0xFF, kPadPostings * 8, ctx->stream);   // docId ~0: never taken
-        if (e == hipSuccess) e = hipMemsetAsync((char*)s->d_pnorm + nbytes / 2, 0, kPadPostings * 4, ctx->stream);
-        if (e == hipSuccess && nbytes) e = stage(s->d_postings, postings, nbytes);
-        if (e == hipSuccess && n_docs) e = stage(d_len, doc_len, (size_t)n_docs * 4);
-        if (e == hipSuccess && n_docs) {
-            hipLaunchKernelGGL(k_norm, dim3((n_docs + 255) / 256), dim3(256), 0, ctx->stream, d_len, s->d_norm, n_docs, avgdl);
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess && s->n_postings) {
-            uint32_t blocks = (uint32_t)std::min<uint64_t>((s->n_postings + 255) / 256, 65536);
-            hipLaunchKernelGGL(k_pnorm, dim3(blocks), dim3(256), 0, ctx->stream, s->d_postings, s->d_norm, s->d_pnorm, s->n_postings, n_docs);
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    e = hipMemsetAsync((char*)s->d_postings + nbytes, 0xFF, kPadPostings * 8, ctx->stream);   // docId ~0: never taken
+    if (e == hipSuccess) e = hipMemsetAsync((char*)s->d_pnorm + nbytes / 2, 0, kPadPostings * 4, ctx->stream);
+    if (e == hipSuccess && n_docs) e = seg_stage(ctx, s, s->d_len, doc_len, (size_t)n_docs * 4);
+    if (e == hipSuccess && n_docs) {
+        hipLaunchKernelGGL(k_norm, dim3((n_docs + 255) / 256), dim3(256), 0, ctx->stream, s->d_len, s->d_norm, n_docs, avgdl);
+        e = hipGetLastError();
     }
-    for (int i = 0; i < 2; i++) {
-        if (pin[i]) (void)hipHostFree(pin[i]);
-        if (ev[i]) (void)hipEventDestroy(ev[i]);
-    }
-    (void)hipFree(d_len);
-    if (!ok) { cleanup(); return fail(ctx, NS_E_NOMEM, "pinned staging allocation failed"); }
-    if (e != hipSuccess) { cleanup(); return fail(ctx, NS_E_HIP, "segment upload: %s", hipGetErrorString(e)); }
-
+    if (e != hipSuccess) { (void)hipStreamSynchronize(ctx->stream); cleanup(); return fail(ctx, NS_E_HIP, "segment upload: %s", hipGetErrorString(e)); }
     {
         // norms are monotone in doc_len (k_norm's expression, evaluated here the same way): the extremes bound them all
         uint32_t dl_min = 0xFFFFFFFFu, dl_max = 0;
@@ -336,22 +347,65 @@ extern "C" int ns_segment_upload(ns_ctx* ctx, uint32_t seg_id, uint32_t n_docs, 
         s->norm_safe = n_docs > 0 && std::isfinite(avgdl) && avgdl > 0.0f && norm_of(dl_min) >= lo_ok && norm_of(dl_min) <= hi_ok &&
                        norm_of(dl_max) >= lo_ok && norm_of(dl_max) <= hi_ok;
     }
-    if (ctx->segs.size() <= seg_id) ctx->segs.resize(seg_id + 1, nullptr);
-    ctx->segs[seg_id] = s;
+    *out = s;
+    return NS_OK;
+}
+
+extern "C" int ns_segment_upload_append(ns_ctx* ctx, ns_seg* s, const void* bytes, uint64_t nbytes) {
+    if (!ctx || !s || s->ctx != ctx || !s->pending) return fail(ctx, NS_E_STATE, "ns_segment_upload_append: no upload in progress for this segment");
+    if (nbytes % 8 != 0) return fail(ctx, NS_E_INVAL, "chunk of %llu bytes is not a whole number of {u32,u32} pairs", (unsigned long long)nbytes);
+    if (s->filled + nbytes > s->n_postings * 8) return fail(ctx, NS_E_INVAL, "chunk runs past the %llu payload bytes announced at begin", (unsigned long long)(s->n_postings * 8));
+    if (nbytes && !bytes) return fail(ctx, NS_E_INVAL, "null doc_len/postings");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const hipError_t e = seg_stage(ctx, s, (char*)s->d_postings + s->filled, bytes, nbytes);
+    if (e != hipSuccess) return fail(ctx, NS_E_HIP, "segment upload: %s", hipGetErrorString(e));
+    s->filled += nbytes;
+    return NS_OK;
+}
+
+extern "C" int ns_segment_upload_end(ns_ctx* ctx, ns_seg* s) {
+    if (!ctx || !s || s->ctx != ctx || !s->pending) return fail(ctx, NS_E_STATE, "ns_segment_upload_end: no upload in progress for this segment");
+    if (s->filled != s->n_postings * 8) return fail(ctx, NS_E_STATE, "ns_segment_upload_end: %llu of %llu payload bytes received", (unsigned long long)s->filled, (unsigned long long)(s->n_postings * 8));
+    if (s->id < ctx->segs.size() && ctx->segs[s->id]) return fail(ctx, NS_E_INVAL, "segment %u already uploaded", s->id);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipSuccess;
+    if (s->n_postings) {
+        uint32_t blocks = (uint32_t)std::min<uint64_t>((s->n_postings + 255) / 256, 65536);
+        hipLaunchKernelGGL(k_pnorm, dim3(blocks), dim3(256), 0, ctx->stream, s->d_postings, s->d_norm, s->d_pnorm, s->n_postings, s->n_docs);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return fail(ctx, NS_E_HIP, "segment upload: %s", hipGetErrorString(e));
+    seg_free_staging(s);
+    s->pending = false;
+    if (ctx->segs.size() <= s->id) ctx->segs.resize(s->id + 1, nullptr);
+    ctx->segs[s->id] = s;
+    return NS_OK;
+}
+
+extern "C" int ns_segment_upload(ns_ctx* ctx, uint32_t seg_id, uint32_t n_docs, float avgdl, const uint32_t* doc_len,
+                                 const void* postings, uint64_t nbytes, ns_seg** out) {
+    if (out) *out = nullptr;
+    if (ctx && nbytes && !postings) return fail(ctx, NS_E_INVAL, "null doc_len/postings");
+    ns_seg* s = nullptr;
+    int rc = ns_segment_upload_begin(ctx, seg_id, n_docs, avgdl, doc_len, nbytes, &s);
+    if (rc != NS_OK) return rc;
+    rc = ns_segment_upload_append(ctx, s, postings, nbytes);
+    if (rc == NS_OK) rc = ns_segment_upload_end(ctx, s);
+    if (rc != NS_OK) { const std::string keep = ctx->err; (void)ns_segment_release(ctx, s); ctx->err = keep; return rc; }
     if (out) *out = s;
     return NS_OK;
 }
 
 extern "C" int ns_segment_release(ns_ctx* ctx, ns_seg* seg) {
     if (!ctx || !seg) return fail(ctx, NS_E_INVAL, "ns_segment_release: null argument");
-    if (seg->id >= ctx->segs.size() || ctx->segs[seg->id] != seg) return fail(ctx, NS_E_INVAL, "segment does not belong to this ctx");
+    if (seg->ctx != ctx) return fail(ctx, NS_E_INVAL, "segment does not belong to this ctx");
+    if (!seg->pending && (seg->id >= ctx->segs.size() || ctx->segs[seg->id] != seg)) return fail(ctx, NS_E_INVAL, "segment does not belong to this ctx");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(seg->d_postings);
-    (void)hipFree(seg->d_norm);
-    (void)hipFree(seg->d_pnorm);
-    (void)hipFree(seg->d_impacts);
-    ctx->segs[seg->id] = nullptr;
+    seg_free_staging(seg);
+    seg_free_device(seg);
+    if (!seg->pending) ctx->segs[seg->id] = nullptr;
     delete seg;
     return NS_OK;
 }
@@ -400,7 +454,6 @@ extern "C" int ns_segment_build_impacts(ns_ctx* ctx, ns_seg* seg, const uint64_t
     for (size_t i = 1; i < lists.size(); i++)
         if (lists[i - 1].first + (uint64_t)lists[i - 1].count > lists[i].first) return fail(ctx, NS_E_INVAL, "lists overlap at posting %u", lists[i].first);
     if (lists.empty()) return NS_OK;
-    const size_t kPadPostings = 256;
     hipError_t e = hipSuccess;
     if (!seg->d_impacts) {
         e = hipMalloc((void**)&seg->d_impacts, (seg->n_postings + kPadPostings) * 8);

@@ -1,6 +1,8 @@
 #include "engine.hpp"
 
 #include <algorithm>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <cmath>
 #include <limits>
@@ -33,18 +35,45 @@ void Engine::release_device_segments() {
     sem.dev = nullptr;
 }
 
+// One segment's postings to the device without a host copy: every inverted file is mapped, appended from the mapping
+// (the C-ABI stages it through pinned memory) and unmapped again.  What the reference's open ifstreams are to it
+// (src/api_segment.cpp:70-102) the device buffer is to this engine.
+static bool upload_segment(ns_ctx* ctx, uint32_t seg_id, nsx::SegmentData& s, ns_seg** out, std::string& err) {
+    if (s.doc_len.size() < s.N) s.doc_len.resize(s.N, 0);   // stats.bin N larger than docs.bin: treat missing as 0
+    ns_seg* dev = nullptr;
+    int rc = ns_segment_upload_begin(ctx, seg_id, s.N, s.avgdl, s.doc_len.data(), s.postings_bytes, &dev);
+    if (rc != NS_OK) { err = std::string("ns_segment_upload: ") + ns_last_error(ctx); return false; }
+    const bool fed = nsx::for_each_inverted_file(s, [&](const uint8_t* p, uint64_t n) {
+        rc = ns_segment_upload_append(ctx, dev, p, n);
+        return rc == NS_OK;
+    });
+    if (fed) rc = ns_segment_upload_end(ctx, dev);
+    if (!fed || rc != NS_OK) {
+        err = rc != NS_OK ? std::string("ns_segment_upload: ") + ns_last_error(ctx)
+                          : "cannot map the inverted files of " + s.dir.string() + " (missing, or changed since they were listed)";
+        (void)ns_segment_release(ctx, dev);
+        return false;
+    }
+    *out = dev;
+    return true;
+}
+
+// reload (src/api_engine.cpp:50-160).  Like the reference, the new state replaces the old one only after EVERYTHING
+// loaded (:76-90): segments, metadata and embeddings are built aside, the device copy goes into a FRESH context, and
+// only then are the old context and the old host state dropped.  A failed reload leaves the engine serving what it
+// served before.  (Old and new device copies coexist during the swap: 2 x index size of HBM, against 288 GB.)
 bool Engine::reload() {
+    std::lock_guard<std::recursive_mutex> lock(mtx_);
     err_.clear();
-    cache_.clear();
-    lru_.clear();
     // manifest, else scan segments/seg_* sorted (src/api_engine.cpp:57-73)
     std::vector<std::string> names = nsx::load_manifest(index_dir / "manifest.bin");
     if (names.empty()) {
         nsx::fs::path segroot = index_dir / "segments";
-        if (nsx::fs::exists(segroot) && nsx::fs::is_directory(segroot)) {
-            for (auto& e : nsx::fs::directory_iterator(segroot)) {
-                if (!e.is_directory()) continue;
-                auto name = e.path().filename().string();
+        std::error_code ec;
+        if (nsx::fs::is_directory(segroot, ec)) {
+            for (auto it = nsx::fs::directory_iterator(segroot, ec); !ec && it != nsx::fs::directory_iterator(); it.increment(ec)) {
+                if (!it->is_directory(ec)) continue;
+                auto name = it->path().filename().string();
                 if (name.rfind("seg_", 0) == 0) names.push_back(name);
             }
             std::sort(names.begin(), names.end());
@@ -57,31 +86,58 @@ bool Engine::reload() {
         nsx::fs::path segdir = index_dir / "segments" / names[i];
         if (!nsx::load_segment(segdir, loaded[i])) { err_ = "failed to load segment: " + segdir.string(); return false; }
     }
-
-    if (device_ >= 0) {
-        if (!ctx_) {
-            int rc = ns_ctx_create(device_, &ctx_);
-            if (rc != NS_OK) { err_ = std::string("ns_ctx_create: ") + ns_last_error(nullptr); ctx_ = nullptr; return false; }
+    // metadata mapping (src/api_engine.cpp:110-113): absent file = no decoration, not an error
+    nsx::MetadataTable fresh_meta;
+    fresh_meta.load(index_dir / "metadata.csv", loaded);
+    // embeddings (src/api_engine.cpp:115-153): only the terms some lexicon holds; absent or unusable file = no expansion
+    nsx::SemanticTable fresh_sem;
+    {
+        nsx::fs::path emb;
+        if (const char* p = std::getenv("EMBEDDINGS_PATH")) {
+            emb = nsx::fs::path(p);
+        } else {
+            for (const char* c : {"embeddings.vec", "embeddings.txt", "glove.txt", "vectors.txt"})
+                if (nsx::fs::exists(index_dir / c)) { emb = index_dir / c; break; }
         }
-        // upload hook: once per segment, after load_segment (src/api_engine.cpp:90)
-        std::vector<ns_seg*> fresh(loaded.size(), nullptr);
-        release_device_segments();
-        for (size_t i = 0; i < loaded.size(); i++) {
-            auto& s = loaded[i];
-            if (s.doc_len.size() < s.N) s.doc_len.resize(s.N, 0);   // stats.bin N larger than docs.bin: treat missing as 0
-            int rc = ns_segment_upload(ctx_, (uint32_t)i, s.N, s.avgdl, s.doc_len.data(), s.postings.data(), s.postings.size() & ~7ull, &fresh[i]);
-            if (rc != NS_OK) {
-                err_ = std::string("ns_segment_upload: ") + ns_last_error(ctx_);
-                for (ns_seg* d : fresh) if (d) ns_segment_release(ctx_, d);
-                return false;
-            }
+        if (!emb.empty() && nsx::fs::exists(emb)) {
+            std::unordered_set<std::string> needed;
+            needed.reserve(250000);
+            for (const auto& seg : loaded)
+                for (const auto& kv : seg.lex) needed.insert(kv.first);
+            fresh_sem.load_from_text(emb, needed);
         }
-        dev_segs_ = std::move(fresh);
     }
+
+    ns_ctx* fresh_ctx = nullptr;
+    std::vector<ns_seg*> fresh_segs;
+    if (device_ >= 0) {
+        int rc = ns_ctx_create(device_, &fresh_ctx);
+        if (rc != NS_OK) { err_ = std::string("ns_ctx_create: ") + ns_last_error(nullptr); return false; }
+        // upload hook: once per segment, after load_segment (src/api_engine.cpp:90)
+        fresh_segs.assign(loaded.size(), nullptr);
+        bool ok = true;
+        for (size_t i = 0; i < loaded.size() && ok; i++) ok = upload_segment(fresh_ctx, (uint32_t)i, loaded[i], &fresh_segs[i], err_);
+        if (ok && fresh_sem.enabled) {
+            rc = ns_sem_upload(fresh_ctx, fresh_sem.vecs.data(), (uint32_t)fresh_sem.terms.size(), (uint32_t)fresh_sem.dim, &fresh_sem.dev);
+            if (rc != NS_OK) { err_ = std::string("ns_sem_upload: ") + ns_last_error(fresh_ctx); ok = false; }
+        }
+        if (!ok) {   // the engine keeps serving the previous index
+            ns_ctx_destroy(fresh_ctx);   // frees the segments it holds
+            return false;
+        }
+    }
+    // ---- commit ----
+    release_device_segments();
+    if (ctx_) ns_ctx_destroy(ctx_);
+    ctx_ = fresh_ctx;
+    dev_segs_ = std::move(fresh_segs);
     seg_names = std::move(names);
     segments = std::move(loaded);
-    // metadata mapping (src/api_engine.cpp:110-113): absent file = no decoration, not an error
-    meta.load(index_dir / "metadata.csv", segments);
+    meta = std::move(fresh_meta);
+    sem = std::move(fresh_sem);
+    cache_.clear();
+    lru_.clear();
+    raw_postings_.clear();
     // warm-up: the first requests after a reload otherwise pay for loading the kernels' code objects and for the
     // pinned staging buffers (~60 ms spread over the first few hundred requests).  One lone query over the longest
     // list of the first segment takes the same route (k_pull, k_uscore, k_merge_wide) once, here.
@@ -99,30 +155,23 @@ bool Engine::reload() {
             (void)ns_search_batch(ctx_, &qd, &r, 1, 10, hits, &nh, &fd, NS_FLAG_OR);
         }
     }
-    // embeddings (src/api_engine.cpp:115-153): only the terms some lexicon holds; absent or unusable file = no expansion
-    sem.clear();
-    {
-        std::unordered_set<std::string> needed;
-        needed.reserve(250000);
-        for (const auto& seg : segments)
-            for (const auto& kv : seg.lex) needed.insert(kv.first);
-        nsx::fs::path emb;
-        if (const char* p = std::getenv("EMBEDDINGS_PATH")) {
-            emb = nsx::fs::path(p);
-        } else {
-            for (const char* c : {"embeddings.vec", "embeddings.txt", "glove.txt", "vectors.txt"})
-                if (nsx::fs::exists(index_dir / c)) { emb = index_dir / c; break; }
-        }
-        if (!emb.empty() && nsx::fs::exists(emb) && sem.load_from_text(emb, needed) && ctx_) {
-            int rc = ns_sem_upload(ctx_, sem.vecs.data(), (uint32_t)sem.terms.size(), (uint32_t)sem.dim, &sem.dev);
-            if (rc != NS_OK) { err_ = std::string("ns_sem_upload: ") + ns_last_error(ctx_); return false; }
-        }
-    }
     return true;
 }
 
-// Query preparation (tokenise, stop-words, lexicon probes, idf: src/api_engine.cpp:388-397,:454-461) for
+const std::vector<uint8_t>* Engine::raw_postings(uint32_t seg) {
+    std::lock_guard<std::recursive_mutex> lock(mtx_);
+    if (seg >= segments.size()) return nullptr;
+    if (raw_postings_.size() < segments.size()) raw_postings_.resize(segments.size());
+    auto& slot = raw_postings_[seg];
+    if (!slot) {
+        slot = std::make_unique<std::vector<uint8_t>>();
+        if (!nsx::read_postings(segments[seg], *slot)) { slot.reset(); err_ = "cannot read the inverted files of " + segments[seg].dir.string(); return nullptr; }
+    }
+    return slot.get();
+}
+
 bool Engine::build_impacts() {
+    std::lock_guard<std::recursive_mutex> lock(mtx_);
     if (!ctx_) { err_ = "no device context"; return false; }
     for (size_t sid = 0; sid < segments.size(); sid++) {
         const auto& seg = segments[sid];
@@ -143,8 +192,9 @@ bool Engine::build_impacts() {
     return true;
 }
 
-void Engine::use_impacts(bool on) { if (ctx_) ns_ctx_use_impacts(ctx_, on ? 1 : 0); }
+void Engine::use_impacts(bool on) { std::lock_guard<std::recursive_mutex> lock(mtx_); if (ctx_) ns_ctx_use_impacts(ctx_, on ? 1 : 0); }
 
+// Query preparation (tokenise, stop-words, lexicon probes, idf: src/api_engine.cpp:388-397,:454-461) for
 // queries [q0, q1); `refs` receives the term refs of those queries, qd[q].term_begin is relative to it.
 void Engine::build_refs_range(const std::vector<std::string>& queries, size_t q0, size_t q1, std::vector<ns_query_desc>& qd,
                               std::vector<ns_term_ref>& refs, std::vector<uint8_t>& usable,
@@ -183,6 +233,7 @@ void Engine::build_refs_range(const std::vector<std::string>& queries, size_t q0
 // term refs are concatenated in query order.
 void Engine::build_refs(const std::vector<std::string>& queries, std::vector<ns_query_desc>& qd,
                         std::vector<ns_term_ref>& refs, std::vector<uint8_t>& usable) const {
+    std::lock_guard<std::recursive_mutex> lock(mtx_);
     const size_t Q = queries.size();
     qd.assign(Q, ns_query_desc{0, 0});
     usable.assign(Q, 0);
@@ -213,6 +264,7 @@ void Engine::build_refs(const std::vector<std::string>& queries, std::vector<ns_
 }
 
 bool Engine::expand_queries(const std::vector<std::string>& queries, std::vector<nsx::WeightedTerms>& out) const {
+    std::lock_guard<std::recursive_mutex> lock(mtx_);
     std::vector<std::vector<std::string>> qt(queries.size());
     for (size_t q = 0; q < queries.size(); q++) qt[q] = base_terms(queries[q]);
     if (!sem.enabled) {
@@ -226,6 +278,7 @@ bool Engine::expand_queries(const std::vector<std::string>& queries, std::vector
 }
 
 bool Engine::prepare(const std::vector<std::string>& queries, int k, uint32_t flags, ns_batch** out) {
+    std::lock_guard<std::recursive_mutex> lock(mtx_);
     if (!ctx_) { err_ = "no device context: this engine has no CPU scoring path"; return false; }
     const int K = std::max(1, std::min(k, 100));   // src/api_engine.cpp:377
     std::vector<ns_query_desc> qd;
@@ -239,6 +292,11 @@ bool Engine::prepare(const std::vector<std::string>& queries, int k, uint32_t fl
 }
 
 bool Engine::search_batch(const std::vector<std::string>& queries, int k, uint32_t flags, std::vector<SearchResult>& out) {
+    std::lock_guard<std::recursive_mutex> lock(mtx_);
+    return search_batch_locked(queries, k, flags, out);
+}
+
+bool Engine::search_batch_locked(const std::vector<std::string>& queries, int k, uint32_t flags, std::vector<SearchResult>& out) {
     out.clear();
     if (!ctx_) { err_ = "no device context: this engine has no CPU scoring path"; return false; }
     const int K = std::max(1, std::min(k, 100));
@@ -272,13 +330,24 @@ bool Engine::search_batch(const std::vector<std::string>& queries, int k, uint32
 }
 
 bool Engine::search_hits(const std::string& query, int k, uint32_t flags, SearchResult& out) {
+    std::lock_guard<std::recursive_mutex> lock(mtx_);
+    return search_hits_locked(query, k, flags, out);
+}
+
+bool Engine::search_hits_locked(const std::string& query, int k, uint32_t flags, SearchResult& out) {
     std::vector<SearchResult> v;
-    if (!search_batch({query}, k, flags, v)) return false;
+    if (!search_batch_locked({query}, k, flags, v)) return false;
     out = std::move(v[0]);
     return true;
 }
 
 std::string Engine::to_json(const SearchResult& r) const {
+    std::lock_guard<std::recursive_mutex> lock(mtx_);
+    return to_json_impl(r);
+}
+
+// no lock: search_batch_json runs it on several threads while the calling thread holds the engine lock
+std::string Engine::to_json_impl(const SearchResult& r) const {
     std::string o;
     o += "{\n";
     if (r.has_found) o += "  \"found\": " + std::to_string(r.found) + ",\n";
@@ -321,23 +390,29 @@ std::string Engine::to_json(const SearchResult& r) const {
 
 bool Engine::search_batch_json(const std::vector<std::string>& queries, int k, std::vector<std::string>& out) {
     std::vector<SearchResult> res;
-    if (!search_batch(queries, k, NS_FLAG_OR, res)) return false;
+    std::lock_guard<std::recursive_mutex> lock(mtx_);
+    if (!search_batch_locked(queries, k, NS_FLAG_OR, res)) return false;
+    // result assembly reads segments / meta, which only reload() replaces: the lock is held to the end
     const size_t Q = res.size();
     out.assign(Q, std::string());
     unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
     nt = (unsigned)std::min<size_t>(nt, Q / 512);
     if (nt <= 1) {
-        for (size_t q = 0; q < Q; q++) out[q] = to_json(res[q]);
+        for (size_t q = 0; q < Q; q++) out[q] = to_json_impl(res[q]);
         return true;
     }
     std::vector<std::thread> th;
     for (unsigned i = 0; i < nt; i++)
-        th.emplace_back([&, i]() { for (size_t q = Q * i / nt; q < Q * (i + 1) / nt; q++) out[q] = to_json(res[q]); });
+        th.emplace_back([&, i]() { for (size_t q = Q * i / nt; q < Q * (i + 1) / nt; q++) out[q] = to_json_impl(res[q]); });
     for (auto& t : th) t.join();
     return true;
 }
 
+// Every engine entry takes the one engine lock, as the reference does (src/api_engine.cpp:372 `std::lock_guard<std::mutex>
+// lock(mtx)`; :54, :168): the HTTP layer calls search() from a thread pool, and the result cache, the error string and
+// the device context (one stream, one set of pinned staging buffers: include/nextsearch_hip.h) are not re-entrant.
 bool Engine::search_text(const std::string& query, int k, std::string& body) {
+    std::lock_guard<std::recursive_mutex> lock(mtx_);
     const int K = std::max(1, std::min(k, 100));
     const std::string key = query + "|" + std::to_string(K);            // make_cache_key (:190-192), K already clamped (:377-380)
     if (cache_on_) {
@@ -354,8 +429,8 @@ bool Engine::search_text(const std::string& query, int k, std::string& body) {
         }
     }
     SearchResult r;
-    if (!search_hits(query, k, NS_FLAG_OR, r)) return false;
-    body = to_json(r);
+    if (!search_hits_locked(query, k, NS_FLAG_OR, r)) { body = err_; return false; }   // the message, for the caller that has no other way to it
+    body = to_json_impl(r);
     if (cache_on_ && r.has_found) {                                     // put_in_cache (:213-250); the early returns (:407,:424) skip it
         if (cache_.size() >= kMaxCacheSize) {
             auto ev = cache_.find(lru_.back());
@@ -372,7 +447,7 @@ std::string Engine::search(const std::string& query, int k) {
     if (!search_text(query, k, body)) {
         // the reference lets exceptions reach the HTTP layer's 500 handler (src/api_server.cpp:76-84)
         std::string o = "{\n  \"error\": ";
-        json_escape(o, err_);
+        json_escape(o, body);
         o += "\n}";
         return o;
     }

@@ -16,6 +16,8 @@
 
 #include <cstdint>
 #include <list>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -67,9 +69,7 @@ public:
     // Search-result cache around search() (src/api_engine.cpp:190-250,:380-385,:539): key "query|K", at most 2600
     // entries, least recently used evicted, a hit returns the stored body plus "from_cache": true.  In memory only:
     // the reference also rewrites search_cache.json in the CWD on every insert (:245-249), which is not reproduced.
-    bool search_text(const std::string& query, int k, std::string& body);   // search() with the failure visible to the caller
-    void set_cache(bool on) { cache_on_ = on; if (!on) { cache_.clear(); lru_.clear(); } }
-    size_t cache_size() const { return cache_.size(); }
+    bool search_text(const std::string& query, int k, std::string& body);   // search() with the failure visible to the caller (body = the message then)
     static constexpr size_t kMaxCacheSize = 2600;               // include/api_engine.hpp:42
     bool search_hits(const std::string& query, int k, uint32_t flags, SearchResult& out);
     bool search_batch(const std::vector<std::string>& queries, int k, uint32_t flags, std::vector<SearchResult>& out);
@@ -88,12 +88,24 @@ public:
     bool prepare(const std::vector<std::string>& queries, int k, uint32_t flags, ns_batch** out);
 
     std::string to_json(const SearchResult& r) const;
+    std::string to_json_impl(const SearchResult& r) const;
     // A batch of searches straight to the /api/search JSON bodies (result assembly on several host threads).
     bool search_batch_json(const std::vector<std::string>& queries, int k, std::vector<std::string>& out);
     ns_ctx* ctx() const { return ctx_; }
-    const std::string& last_error() const { return err_; }
+    std::string last_error() const { std::lock_guard<std::recursive_mutex> lock(mtx_); return err_; }
+    void set_cache(bool on) { std::lock_guard<std::recursive_mutex> lock(mtx_); cache_on_ = on; if (!on) { cache_.clear(); lru_.clear(); } }
+    size_t cache_size() const { std::lock_guard<std::recursive_mutex> lock(mtx_); return cache_.size(); }
+    // The raw posting payload of a segment in host memory, read from the inverted files on first request (tests and
+    // tools; the engine itself never holds it: reload() streams the files to the device from their mappings).
+    const std::vector<uint8_t>* raw_postings(uint32_t seg);
 
 private:
+    // The reference's Engine::mtx (include/api_engine.hpp:33, taken at src/api_engine.cpp:54,:168,:372): one lock around
+    // every entry that touches the cache, the error string, the device context or the loaded index.
+    mutable std::recursive_mutex mtx_;   // recursive: public entries call each other (search -> build_refs -> expand_queries)
+    bool search_batch_locked(const std::vector<std::string>& queries, int k, uint32_t flags, std::vector<SearchResult>& out);
+    bool search_hits_locked(const std::string& query, int k, uint32_t flags, SearchResult& out);
+    std::vector<std::unique_ptr<std::vector<uint8_t>>> raw_postings_;
     void release_device_segments();
     struct CacheEntry { std::string body; std::list<std::string>::iterator lru; };
     std::unordered_map<std::string, CacheEntry> cache_;

@@ -1,4 +1,6 @@
 // C wrappers of include/nextsearch_host.h over nextsearch::Engine.
+// No C++ exception crosses the boundary: every entry runs inside try/catch (std::filesystem errors, bad_alloc on a
+// corrupt count, ...) and reports failure through its return value and nsh_engine_error().
 #include "invert.hpp"
 #include <cstdlib>
 #include <cstring>
@@ -15,6 +17,16 @@ struct nsh_engine {
     std::string err;
     explicit nsh_engine(int device) : eng(device) {}
 };
+
+static void nsh_note(nsh_engine* e, const char* where, const char* what) {
+    if (e) e->err = std::string(where) + ": " + what;
+}
+#define NSH_CATCH(e, where, failval)                                                        \
+    catch (const std::exception& ex_) { nsh_note((e), (where), ex_.what()); return failval; } \
+    catch (...) { nsh_note((e), (where), "unknown exception"); return failval; }
+#define NSH_CATCH_VOID(e, where)                                          \
+    catch (const std::exception& ex_) { nsh_note((e), (where), ex_.what()); } \
+    catch (...) { nsh_note((e), (where), "unknown exception"); }
 
 static std::vector<std::string> to_vec(const char* const* qs, uint32_t n) {
     std::vector<std::string> v(n);
@@ -40,31 +52,44 @@ extern "C" int nsh_gen_index(const char* index_dir, uint32_t n_segments, uint32_
     }
 }
 
-extern "C" int nsh_engine_open(const char* index_dir, int device, nsh_engine** out) {
+extern "C" int nsh_engine_open(const char* index_dir, int device, nsh_engine** out) { try {
     if (!out) return -1;
     nsh_engine* e = new nsh_engine(device);
     e->eng.index_dir = index_dir ? index_dir : "";
     *out = e;
     if (!e->eng.reload()) { e->err = e->eng.last_error(); return -1; }
     return 0;
+} NSH_CATCH(out ? *out : nullptr, "nsh_engine_open", -1)
 }
 
 extern "C" void nsh_engine_close(nsh_engine* e) { delete e; }
-extern "C" const char* nsh_engine_error(nsh_engine* e) {
+// Engine::reload() (include/api_engine.hpp:65) on the directory given at open: 0 on success; on failure the engine
+// keeps serving what it served before and nsh_engine_error() says why.
+extern "C" int nsh_engine_reload(nsh_engine* e) { try {
+    if (!e) return -1;
+    if (!e->eng.reload()) { e->err = e->eng.last_error(); return -1; }
+    return 0;
+} NSH_CATCH(e, "nsh_engine_reload", -1)
+}
+extern "C" const char* nsh_engine_error(nsh_engine* e) { try {
     if (!e) return "null engine";
     if (!e->eng.last_error().empty()) e->err = e->eng.last_error();
     return e->err.c_str();
+} NSH_CATCH(e, "nsh_engine_error", "")
 }
-extern "C" ns_ctx* nsh_engine_ctx(nsh_engine* e) { return e ? e->eng.ctx() : nullptr; }
-extern "C" uint32_t nsh_engine_num_segments(nsh_engine* e) { return e ? (uint32_t)e->eng.segments.size() : 0; }
-extern "C" const char* nsh_engine_segment_name(nsh_engine* e, uint32_t seg) {
+extern "C" ns_ctx* nsh_engine_ctx(nsh_engine* e) { try { return e ? e->eng.ctx() : nullptr;  } NSH_CATCH(e, "nsh_engine_ctx", nullptr)
+}
+extern "C" uint32_t nsh_engine_num_segments(nsh_engine* e) { try { return e ? (uint32_t)e->eng.segments.size() : 0;  } NSH_CATCH(e, "nsh_engine_num_segments", 0)
+}
+extern "C" const char* nsh_engine_segment_name(nsh_engine* e, uint32_t seg) { try {
     return (e && seg < e->eng.seg_names.size()) ? e->eng.seg_names[seg].c_str() : "";
+} NSH_CATCH(e, "nsh_engine_segment_name", "")
 }
 
 // Result decoration (src/api_engine.cpp:516-531): the four fields of a document, valid until close/reload.
 // Returns 1 if the document has a metadata row, else 0 (all four then point to "").
 extern "C" int nsh_engine_doc_metadata(nsh_engine* e, uint32_t seg, uint32_t doc, const char** title, const char** url,
-                                       const char** publish_time, const char** author) {
+                                       const char** publish_time, const char** author) { try {
     static const char* kEmpty = "";
     const nsx::MetaFields* m = e ? e->eng.meta.get(seg, doc) : nullptr;
     if (title) *title = m ? m->title.c_str() : kEmpty;
@@ -72,10 +97,11 @@ extern "C" int nsh_engine_doc_metadata(nsh_engine* e, uint32_t seg, uint32_t doc
     if (publish_time) *publish_time = m ? m->publish_time.c_str() : kEmpty;
     if (author) *author = m ? m->author.c_str() : kEmpty;
     return m ? 1 : 0;
+} NSH_CATCH(e, "nsh_engine_doc_metadata", -1)
 }
 // JSON text of one result assembled from given hits (the decoration + serialisation step alone; no device needed).
 extern "C" int nsh_engine_hits_to_json(nsh_engine* e, const char* query, int k, int has_found, uint64_t found,
-                                       const ns_hit* hits, uint32_t nhits, char** json_out) {
+                                       const ns_hit* hits, uint32_t nhits, char** json_out) { try {
     if (!e || !json_out) return -1;
     nextsearch::SearchResult r;
     r.query = query ? query : "";
@@ -83,38 +109,48 @@ extern "C" int nsh_engine_hits_to_json(nsh_engine* e, const char* query, int k, 
     r.segments = (int)e->eng.segments.size();
     r.has_found = has_found != 0;
     r.found = found;
-    for (uint32_t i = 0; i < nhits; i++) r.hits.push_back(nextsearch::SearchHit{hits[i].score, hits[i].seg_id, hits[i].doc_id});
+    if (nhits && !hits) return -1;
+    for (uint32_t i = 0; i < nhits; i++) {
+        if (hits[i].seg_id >= e->eng.segments.size()) { e->err = "nsh_engine_hits_to_json: hit names a segment that is not loaded"; return -1; }
+        r.hits.push_back(nextsearch::SearchHit{hits[i].score, hits[i].seg_id, hits[i].doc_id});
+    }
     const std::string js = e->eng.to_json(r);
     char* out = (char*)std::malloc(js.size() + 1);
     if (!out) return -1;
     std::memcpy(out, js.c_str(), js.size() + 1);
     *json_out = out;
     return 0;
+} NSH_CATCH(e, "nsh_engine_hits_to_json", -1)
 }
 
 extern "C" int nsh_engine_segment_info(nsh_engine* e, uint32_t seg, uint32_t* n_docs, float* avgdl, uint64_t* n_postings,
-                                       uint32_t* n_terms, int* use_barrels) {
+                                       uint32_t* n_terms, int* use_barrels) { try {
     if (!e || seg >= e->eng.segments.size()) return -1;
     const auto& s = e->eng.segments[seg];
     if (n_docs) *n_docs = s.N;
     if (avgdl) *avgdl = s.avgdl;
-    if (n_postings) *n_postings = s.postings.size() / 8;
+    if (n_postings) *n_postings = s.postings_bytes / 8;
     if (n_terms) *n_terms = (uint32_t)s.lex.size();
     if (use_barrels) *use_barrels = s.use_barrels ? 1 : 0;
     return 0;
+} NSH_CATCH(e, "nsh_engine_segment_info", -1)
 }
 
-extern "C" const uint32_t* nsh_engine_segment_doc_len(nsh_engine* e, uint32_t seg) {
+extern "C" const uint32_t* nsh_engine_segment_doc_len(nsh_engine* e, uint32_t seg) { try {
     return (e && seg < e->eng.segments.size()) ? e->eng.segments[seg].doc_len.data() : nullptr;
+} NSH_CATCH(e, "nsh_engine_segment_doc_len", nullptr)
 }
-extern "C" const void* nsh_engine_segment_postings(nsh_engine* e, uint32_t seg, uint64_t* nbytes) {
+extern "C" const void* nsh_engine_segment_postings(nsh_engine* e, uint32_t seg, uint64_t* nbytes) { try {
     if (!e || seg >= e->eng.segments.size()) return nullptr;
-    if (nbytes) *nbytes = e->eng.segments[seg].postings.size();
-    return e->eng.segments[seg].postings.data();
+    const std::vector<uint8_t>* raw = e->eng.raw_postings(seg);   // read from the inverted files on first request
+    if (!raw) return nullptr;
+    if (nbytes) *nbytes = raw->size();
+    return raw->data();
+} NSH_CATCH(e, "nsh_engine_segment_postings", nullptr)
 }
 
 extern "C" int nsh_engine_lookup(nsh_engine* e, uint32_t seg, const char* term, uint32_t* term_id, uint32_t* df,
-                                 uint32_t* count, uint64_t* byte_off, float* idf) {
+                                 uint32_t* count, uint64_t* byte_off, float* idf) { try {
     if (!e || seg >= e->eng.segments.size() || !term) return 0;
     const auto& s = e->eng.segments[seg];
     auto it = s.lex.find(term);
@@ -126,11 +162,12 @@ extern "C" int nsh_engine_lookup(nsh_engine* e, uint32_t seg, const char* term, 
     if (byte_off) *byte_off = s.list_byte_offset(le);
     if (idf) *idf = nextsearch::bm25_idf(s.N, le.df);
     return 1;
+} NSH_CATCH(e, "nsh_engine_lookup", -1)
 }
 
-extern "C" float nsh_bm25_idf(uint32_t n_docs, uint32_t df) { return nextsearch::bm25_idf(n_docs, df); }
+extern "C" float nsh_bm25_idf(uint32_t n_docs, uint32_t df) { return nextsearch::bm25_idf(n_docs, df); }   // arithmetic only
 
-extern "C" uint32_t nsh_base_terms(const char* query, char* buf, uint32_t cap) {
+extern "C" uint32_t nsh_base_terms(const char* query, char* buf, uint32_t cap) { try {
     auto terms = nextsearch::base_terms(query ? query : "");
     std::string joined;
     for (size_t i = 0; i < terms.size(); i++) {
@@ -143,10 +180,11 @@ extern "C" uint32_t nsh_base_terms(const char* query, char* buf, uint32_t cap) {
         buf[n] = 0;
     }
     return (uint32_t)terms.size();
+} NSH_CATCH(nullptr, "nsh_base_terms", 0)
 }
 
 extern "C" int nsh_engine_build_refs(nsh_engine* e, const char* const* queries, uint32_t n_queries, ns_query_desc* qd,
-                                     ns_term_ref* refs, uint32_t refs_cap, uint32_t* n_refs, uint8_t* usable) {
+                                     ns_term_ref* refs, uint32_t refs_cap, uint32_t* n_refs, uint8_t* usable) { try {
     if (!e) return -1;
     std::vector<ns_query_desc> q;
     std::vector<ns_term_ref> r;
@@ -158,9 +196,10 @@ extern "C" int nsh_engine_build_refs(nsh_engine* e, const char* const* queries, 
     if (r.size() > refs_cap) return 1;
     if (refs && !r.empty()) std::memcpy(refs, r.data(), r.size() * sizeof(ns_term_ref));
     return 0;
+} NSH_CATCH(e, "nsh_engine_build_refs", -1)
 }
 
-extern "C" int nsh_engine_search_json(nsh_engine* e, const char* query, int k, char** json_out) {
+extern "C" int nsh_engine_search_json(nsh_engine* e, const char* query, int k, char** json_out) { try {
     if (!e || !json_out) return -1;
     std::string s;
     const bool ok = e->eng.search_text(query ? query : "", k, s);   // Engine::search: the result cache included
@@ -168,14 +207,15 @@ extern "C" int nsh_engine_search_json(nsh_engine* e, const char* query, int k, c
     *json_out = (char*)std::malloc(s.size() + 1);
     std::memcpy(*json_out, s.c_str(), s.size() + 1);
     return 0;
+} NSH_CATCH(e, "nsh_engine_search_json", -1)
 }
 
 // Batch of searches to JSON bodies: *text_out receives all bodies back to back (free with nsh_free),
 // offsets[q] .. offsets[q+1] delimit body q (offsets has n_queries + 1 entries).
 extern "C" int nsh_engine_search_batch_json(nsh_engine* e, const char* const* queries, uint32_t n_queries, int k,
-                                            char** text_out, uint64_t* offsets) {
+                                            char** text_out, uint64_t* offsets) { try {
     if (!e || !text_out || !offsets) return -1;
-    std::vector<std::string> qs(queries, queries + n_queries), bodies;
+    std::vector<std::string> qs = to_vec(queries, n_queries), bodies;
     if (!e->eng.search_batch_json(qs, k, bodies)) { e->err = e->eng.last_error(); return -1; }
     size_t total = 0;
     for (auto& b : bodies) total += b.size();
@@ -191,11 +231,12 @@ extern "C" int nsh_engine_search_batch_json(nsh_engine* e, const char* const* qu
     buf[pos] = 0;
     *text_out = buf;
     return 0;
+} NSH_CATCH(e, "nsh_engine_search_batch_json", -1)
 }
 extern "C" void nsh_free(void* p) { std::free(p); }
 
 extern "C" int nsh_engine_search_batch(nsh_engine* e, const char* const* queries, uint32_t n_queries, int k, uint32_t flags,
-                                       ns_hit* hits, uint32_t* nhits, uint64_t* found, uint8_t* has_found) {
+                                       ns_hit* hits, uint32_t* nhits, uint64_t* found, uint8_t* has_found) { try {
     if (!e) return -1;
     std::vector<nextsearch::SearchResult> res;
     if (!e->eng.search_batch(to_vec(queries, n_queries), k, flags, res)) { e->err = e->eng.last_error(); return -1; }
@@ -215,13 +256,14 @@ extern "C" int nsh_engine_search_batch(nsh_engine* e, const char* const* queries
         }
     }
     return 0;
+} NSH_CATCH(e, "nsh_engine_search_batch", -1)
 }
 
 // The reference's `lexicon <SEGMENT_DIR>` tool with the inversion on the device (host/invert.hpp).
 static thread_local std::string g_invert_err;
 extern "C" const char* nsh_invert_error() { return g_invert_err.c_str(); }
 extern "C" int nsh_invert_segment(const char* seg_dir, int device, uint64_t* pairs, uint64_t* kept, float* device_ms,
-                                  double* call_s, double* total_s) {
+                                  double* call_s, double* total_s) { try {
     if (!seg_dir) return -1;
     ns_ctx* ctx = nullptr;
     if (ns_ctx_create(device, &ctx) != NS_OK) { g_invert_err = std::string("ns_ctx_create: ") + ns_last_error(nullptr); return -1; }
@@ -234,17 +276,26 @@ extern "C" int nsh_invert_segment(const char* seg_dir, int device, uint64_t* pai
     if (call_s) *call_s = st.call_s;
     if (total_s) *total_s = st.total_s;
     return ok ? 0 : -1;
+} NSH_CATCH(nullptr, "nsh_invert_segment", -1)
 }
 
 // Semantic expansion (src/api_engine.cpp:409-417): rows/dim of the loaded embedding table (0/0: none), and the
 // weighted terms a query is scored with, one "term<TAB>fp32 weight bits in hex" line each, in scoring order.
-extern "C" int nsh_engine_semantic_info(nsh_engine* e, uint32_t* rows, uint32_t* dim) {
+extern "C" int nsh_engine_semantic_info(nsh_engine* e, uint32_t* rows, uint32_t* dim) { try {
     if (!e) return -1;
     if (rows) *rows = e->eng.sem.enabled ? (uint32_t)e->eng.sem.terms.size() : 0;
     if (dim) *dim = e->eng.sem.enabled ? (uint32_t)e->eng.sem.dim : 0;
     return e->eng.sem.enabled ? 1 : 0;
+} NSH_CATCH(e, "nsh_engine_semantic_info", -1)
 }
-extern "C" int nsh_engine_expand(nsh_engine* e, const char* query, char** text_out) {
+extern "C" int nsh_engine_semantic_row(nsh_engine* e, uint32_t row, const char** term, const float** vec) { try {
+    if (!e || !e->eng.sem.enabled || row >= e->eng.sem.terms.size()) return -1;
+    if (term) *term = e->eng.sem.terms[row].c_str();
+    if (vec) *vec = e->eng.sem.vecs.data() + (size_t)row * (size_t)e->eng.sem.dim;
+    return 0;
+} NSH_CATCH(e, "nsh_engine_semantic_row", -1)
+}
+extern "C" int nsh_engine_expand(nsh_engine* e, const char* query, char** text_out) { try {
     if (!e || !query || !text_out) return -1;
     std::vector<nsx::WeightedTerms> w;
     if (!e->eng.expand_queries({std::string(query)}, w)) { e->err = e->eng.last_error(); return -1; }
@@ -260,22 +311,28 @@ extern "C" int nsh_engine_expand(nsh_engine* e, const char* query, char** text_o
     if (!*text_out) return -1;
     std::memcpy(*text_out, o.c_str(), o.size() + 1);
     return 0;
+} NSH_CATCH(e, "nsh_engine_expand", -1)
 }
 
 // Search-result cache of Engine::search (src/api_engine.cpp:190-250): on by default as in the reference.
-extern "C" void nsh_engine_set_cache(nsh_engine* e, int on) { if (e) e->eng.set_cache(on != 0); }
-extern "C" uint32_t nsh_engine_cache_size(nsh_engine* e) { return e ? (uint32_t)e->eng.cache_size() : 0; }
+extern "C" void nsh_engine_set_cache(nsh_engine* e, int on) { try { if (e) e->eng.set_cache(on != 0);  } NSH_CATCH_VOID(e, "nsh_engine_set_cache")
+}
+extern "C" uint32_t nsh_engine_cache_size(nsh_engine* e) { try { return e ? (uint32_t)e->eng.cache_size() : 0;  } NSH_CATCH(e, "nsh_engine_cache_size", 0)
+}
 
-extern "C" int nsh_engine_build_impacts(nsh_engine* e) {
+extern "C" int nsh_engine_build_impacts(nsh_engine* e) { try {
     if (!e) return -1;
     if (!e->eng.build_impacts()) { e->err = e->eng.last_error(); return -1; }
     return 0;
+} NSH_CATCH(e, "nsh_engine_build_impacts", -1)
 }
-extern "C" void nsh_engine_use_impacts(nsh_engine* e, int on) { if (e) e->eng.use_impacts(on != 0); }
+extern "C" void nsh_engine_use_impacts(nsh_engine* e, int on) { try { if (e) e->eng.use_impacts(on != 0);  } NSH_CATCH_VOID(e, "nsh_engine_use_impacts")
+}
 
 extern "C" int nsh_engine_prepare(nsh_engine* e, const char* const* queries, uint32_t n_queries, int k, uint32_t flags,
-                                  ns_batch** out) {
+                                  ns_batch** out) { try {
     if (!e || !out) return -1;
     if (!e->eng.prepare(to_vec(queries, n_queries), k, flags, out)) { e->err = e->eng.last_error(); return -1; }
     return 0;
+} NSH_CATCH(e, "nsh_engine_prepare", -1)
 }

@@ -10,18 +10,25 @@
 //   legacy lexicon.bin/inverted.bin  src/api_segment.cpp:45-67      same records, one file, no barrels
 //   string = u32 len + bytes     include/indexio.hpp:18-29          little-endian, no padding
 //
-// Unlike the reference loader (which keeps 64 open ifstreams and seeks per term), this loader reads
-// every inverted file once and flattens the barrels into ONE contiguous posting buffer plus a
-// barrel_base[] table, because that buffer is what gets staged to HBM (include/nextsearch_hip.h).
+// Like the reference loader (which keeps 64 open ifstreams and seeks per term, src/api_segment.cpp:70-102) this one
+// does not hold the posting payload in host memory: it records each inverted file's size, lays the files out back to
+// back in ONE logical posting buffer (barrel_base[]), and for_each_inverted_file() maps them one at a time so that
+// the caller can feed the device's pinned staging copy straight from the page cache (include/nextsearch_hip.h:
+// ns_segment_upload_begin / _append / _end).
 #pragma once
 
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <fcntl.h>
 #include <filesystem>
+#include <functional>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <vector>
 
 namespace nsx {
@@ -49,13 +56,67 @@ struct SegmentData {
     bool use_barrels = false;
     uint32_t barrel_count = 0;
     uint32_t terms_per_barrel = 0;
-    std::vector<uint64_t> barrel_base;   // byte offset of each inverted file inside `postings`
-    std::vector<uint8_t> postings;       // all inverted files back to back
-    // absolute byte offset of a term's list inside `postings`
+    // The posting payload = all inverted files back to back (never resident on the host as a whole):
+    std::vector<fs::path> inv_files;     // inverted_b000.bin .. (or the one inverted.bin), in payload order
+    std::vector<uint64_t> inv_bytes;     // size of each, rounded down to whole {u32,u32} pairs
+    std::vector<uint64_t> barrel_base;   // byte offset of each inverted file inside the payload
+    uint64_t postings_bytes = 0;         // total payload size
+    // absolute byte offset of a term's list inside the payload
     uint64_t list_byte_offset(const LexEntry& e) const {
         return (use_barrels ? barrel_base[e.barrelId] : 0) + e.offset;
     }
 };
+
+// Read-only mapping of a whole file (the posting payload is consumed from the page cache, not from a private copy).
+class MappedFile {
+public:
+    MappedFile() = default;
+    MappedFile(const MappedFile&) = delete;
+    MappedFile& operator=(const MappedFile&) = delete;
+    ~MappedFile() { close(); }
+    bool open(const fs::path& p) {
+        close();
+        const int fd = ::open(p.c_str(), O_RDONLY | O_CLOEXEC);
+        if (fd < 0) return false;
+        struct stat st;
+        if (::fstat(fd, &st) != 0) { ::close(fd); return false; }
+        size_ = (size_t)st.st_size;
+        if (size_) {
+            void* m = ::mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { ::close(fd); size_ = 0; return false; }
+            (void)::madvise(m, size_, MADV_SEQUENTIAL);
+            base_ = m;
+        }
+        ::close(fd);   // the mapping keeps the file
+        return true;
+    }
+    void close() {
+        if (base_) ::munmap(base_, size_);
+        base_ = nullptr; size_ = 0;
+    }
+    const uint8_t* data() const { return (const uint8_t*)base_; }
+    size_t size() const { return size_; }
+private:
+    void* base_ = nullptr;
+    size_t size_ = 0;
+};
+
+// Hands the payload to `sink` piece by piece, in payload order: each inverted file is mapped, passed on and unmapped.
+// Returns false if a file cannot be mapped or has changed size since load_segment, or when the sink returns false.
+inline bool for_each_inverted_file(const SegmentData& s, const std::function<bool(const uint8_t*, uint64_t)>& sink) {
+    for (size_t i = 0; i < s.inv_files.size(); i++) {
+        MappedFile m;
+        if (!m.open(s.inv_files[i]) || (m.size() & ~(size_t)7) != s.inv_bytes[i]) return false;
+        if (s.inv_bytes[i] && !sink(m.data(), s.inv_bytes[i])) return false;
+    }
+    return true;
+}
+// The whole payload in one host buffer — for tests and tools that look at raw postings; the engine never does this.
+inline bool read_postings(const SegmentData& s, std::vector<uint8_t>& out) {
+    out.clear();
+    out.reserve(s.postings_bytes);
+    return for_each_inverted_file(s, [&](const uint8_t* p, uint64_t n) { out.insert(out.end(), p, p + n); return true; });
+}
 
 // ---- little-endian file reader over a whole-file buffer -------------------------------------
 class FileBytes {
@@ -117,6 +178,7 @@ inline std::vector<std::string> load_manifest(const fs::path& p) {
     FileBytes in;
     if (!fs::exists(p) || !in.load(p)) return segs;
     uint32_t n = in.u32();
+    if ((uint64_t)n * 4 > in.size()) return segs;               // corrupt count
     segs.reserve(n);
     for (uint32_t i = 0; i < n; i++) segs.push_back(in.str());
     return segs;
@@ -124,6 +186,7 @@ inline std::vector<std::string> load_manifest(const fs::path& p) {
 
 inline void read_lexicon_records(FileBytes& in, uint32_t barrel, std::unordered_map<std::string, LexEntry>& lex) {
     uint32_t tcount = in.u32();
+    if ((uint64_t)tcount * 24 > in.size()) tcount = (uint32_t)(in.size() / 24);   // a record takes >= 24 bytes; reads past the end yield nothing anyway
     for (uint32_t i = 0; i < tcount; i++) {
         std::string term = in.str();
         LexEntry e;
@@ -136,7 +199,7 @@ inline void read_lexicon_records(FileBytes& in, uint32_t barrel, std::unordered_
     }
 }
 
-// Mirrors load_segment (src/api_segment.cpp:105-136) but slurps the posting payload.
+// Mirrors load_segment (src/api_segment.cpp:105-136): stats, docs, lexicon in memory; the inverted files stay on disk.
 inline bool load_segment(const fs::path& segdir, SegmentData& s) {
     s = SegmentData{};
     s.dir = segdir;
@@ -151,6 +214,7 @@ inline bool load_segment(const fs::path& segdir, SegmentData& s) {
         FileBytes in;
         if (!in.load(segdir / "docs.bin")) return false;
         uint32_t n = in.u32();
+        if ((uint64_t)n * 16 > in.size()) return false;          // a document record takes >= 16 bytes: the count is corrupt
         s.doc_len.resize(n);
         s.cord_uid.resize(n);
         for (uint32_t i = 0; i < n; i++) {
@@ -160,18 +224,26 @@ inline bool load_segment(const fs::path& segdir, SegmentData& s) {
             s.doc_len[i] = in.u32();
         }
     }
+    auto add_inverted = [&](const fs::path& p) -> bool {
+        std::error_code ec;
+        const uint64_t n = (uint64_t)fs::file_size(p, ec);
+        if (ec) return false;
+        s.inv_files.push_back(p);
+        s.inv_bytes.push_back(n & ~7ull);
+        s.postings_bytes += n & ~7ull;
+        return true;
+    };
     if (has_barrels(segdir)) {
         s.use_barrels = true;
         FileBytes bm;
         if (!bm.load(segdir / "barrels.bin")) return false;
         s.barrel_count = bm.u32();
         s.terms_per_barrel = bm.u32();
+        if (s.barrel_count > 4096) return false;                 // the reference writes 64 (include/barrels.hpp:12): a corrupt header
         s.barrel_base.assign(s.barrel_count, 0);
         for (uint32_t b = 0; b < s.barrel_count; b++) {
-            FileBytes inv;
-            if (!inv.load(inv_barrel_path(segdir, b))) return false;
-            s.barrel_base[b] = s.postings.size();
-            s.postings.insert(s.postings.end(), inv.bytes().begin(), inv.bytes().end());
+            s.barrel_base[b] = s.postings_bytes;
+            if (!add_inverted(inv_barrel_path(segdir, b))) return false;
         }
         for (uint32_t b = 0; b < s.barrel_count; b++) {
             FileBytes in;
@@ -185,10 +257,7 @@ inline bool load_segment(const fs::path& segdir, SegmentData& s) {
     FileBytes in;
     if (!in.load(segdir / "lexicon.bin")) return false;
     read_lexicon_records(in, 0, s.lex);
-    FileBytes inv;
-    if (!inv.load(segdir / "inverted.bin")) return false;
-    s.postings = std::move(inv.bytes());
-    return true;
+    return add_inverted(segdir / "inverted.bin");
 }
 
 // ---- writer ---------------------------------------------------------------------------------

@@ -21,8 +21,12 @@
 
 #include <cctype>
 #include <cstdint>
+#include <cstdlib>
 #include <string>
+#include <string_view>
+#include <thread>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "index_format.hpp"
@@ -33,54 +37,68 @@ struct MetaFields {   // what one hit gets; empty = key absent from the JSON
     std::string title, url, publish_time, author;
 };
 
-inline void csv_split(const char* p, size_t n, std::vector<std::string>& out) {
-    out.clear();
-    std::string cur;
-    bool inq = false;
-    for (size_t i = 0; i < n; i++) {
-        const char c = p[i];
-        if (c == '"') { inq = !inq; continue; }
-        if (!inq && c == ',') { out.push_back(cur); cur.clear(); continue; }
-        cur.push_back(c);
+// One CSV record cut into fields.  The fields' bytes live back to back in ONE buffer (quotes already gone); field i
+// is the span [cut[i], cut[i + 1]).  Rules (src/api_metadata.cpp:13-43): a '"' flips the quoted state and vanishes,
+// a ',' outside quotes ends a field, nothing is escaped; a record always has at least one field.
+struct CsvRecord {
+    std::string bytes;
+    std::vector<uint32_t> cut;
+    void parse(std::string_view line) {
+        bytes.clear();
+        cut.assign(1, 0u);
+        bytes.reserve(line.size());
+        unsigned quoted = 0;
+        for (const char ch : line) {
+            if (ch == '"') quoted ^= 1u;
+            else if (ch == ',' && !quoted) cut.push_back((uint32_t)bytes.size());
+            else bytes.push_back(ch);
+        }
+        cut.push_back((uint32_t)bytes.size());
     }
-    out.push_back(cur);
-}
+    size_t size() const { return cut.size() - 1; }
+    std::string_view operator[](size_t i) const { return std::string_view(bytes).substr(cut[i], cut[i + 1] - cut[i]); }
+    // field i, or nothing when the record is too short or the column does not exist (col < 0)
+    std::string_view at(int col) const { return (col >= 0 && (size_t)col < size()) ? (*this)[(size_t)col] : std::string_view(); }
+};
 
-inline std::string trim_ws(const std::string& s) {
-    size_t a = 0, b = s.size();
-    while (a < b && std::isspace((unsigned char)s[a])) a++;
-    while (b > a && std::isspace((unsigned char)s[b - 1])) b--;
-    return s.substr(a, b - a);
+namespace detail {
+// the "C" locale's isspace set (what the reference's std::isspace sees): ' ', \t \n \v \f \r
+constexpr bool blank(char c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
+inline std::string_view strip(std::string_view v) {
+    while (!v.empty() && blank(v.front())) v.remove_prefix(1);
+    while (!v.empty() && blank(v.back())) v.remove_suffix(1);
+    return v;
 }
+}  // namespace detail
 
-// "Surname et al." from the CORD-19 authors column ("Surname, Given; Surname2, Given2" or "Given Surname")
-inline std::string first_author_et_al(const std::string& raw) {
-    std::string s = trim_ws(raw);
-    if (s.empty()) return "";
-    const size_t semi = s.find(';');
-    std::string first = trim_ws(semi == std::string::npos ? s : s.substr(0, semi));
-    while (!first.empty() && (first.back() == ',' || std::isspace((unsigned char)first.back()))) first.pop_back();
-    first = trim_ws(first);
-    if (first.empty()) return "";
-    if (first.front() == '(') {   // romanised name in parentheses
-        const size_t close = first.find(')');
-        if (close != std::string::npos && close > 1) {
-            const std::string inside = trim_ws(first.substr(1, close - 1));
-            if (!inside.empty()) first = inside;
+// The "author" field of a hit (src/api_metadata.cpp:58-106): the surname of the first author of CORD-19's
+// `authors` column plus " et al.", or nothing.  Authors are ';'-separated; one author is "Surname, Given" or
+// "Given ... Surname"; a leading "(...)" holds a romanised spelling that replaces the whole author when non-blank.
+inline std::string first_author_et_al(std::string_view authors) {
+    using detail::strip;
+    std::string_view who = strip(authors);
+    who = strip(who.substr(0, who.find(';')));                       // find() == npos keeps everything
+    while (!who.empty() && (who.back() == ',' || detail::blank(who.back()))) who.remove_suffix(1);
+    who = strip(who);
+    if (who.empty()) return {};
+    if (who.front() == '(') {
+        const size_t rp = who.find(')');
+        if (rp != std::string_view::npos && rp > 1) {
+            const std::string_view roman = strip(who.substr(1, rp - 1));
+            if (!roman.empty()) who = roman;
         }
     }
-    std::string surname;
-    const size_t comma = first.find(',');
-    if (comma != std::string::npos) {
-        surname = trim_ws(first.substr(0, comma));
+    std::string_view family;
+    if (const size_t c = who.find(','); c != std::string_view::npos) {
+        family = strip(who.substr(0, c));
     } else {
-        const std::string tmp = trim_ws(first);
-        const size_t sp = tmp.find_last_of(" \t");
-        surname = (sp == std::string::npos) ? tmp : trim_ws(tmp.substr(sp + 1));
+        const size_t gap = who.find_last_of(" \t");
+        family = strip(gap == std::string_view::npos ? who : who.substr(gap + 1));
     }
-    surname = trim_ws(surname);
-    if (surname.empty()) return "";
-    return surname + " et al.";
+    if (family.empty()) return {};
+    std::string label(family);
+    label += " et al.";
+    return label;
 }
 
 class MetadataTable {
@@ -91,64 +109,103 @@ public:
 
     void clear() { doc_row.clear(); rows_.assign(1, MetaFields{}); rows_loaded = rows_in_file = 0; }
 
-    // `wanted`: cord_uid -> every (segment, docId) that carries it
-    bool load(const fs::path& csv, const std::vector<SegmentData>& segments) {
+    // Reads <index>/metadata.csv once.  The file is cut at line ends into one slice per host thread; every slice
+    // parses its physical lines on its own (the header's column numbers and the uid -> documents map are read-only),
+    // and the slices' rows are then merged in FILE ORDER, which is what "the first row of a cord_uid wins" refers to.
+    bool load(const fs::path& csv, const std::vector<SegmentData>& segments, unsigned max_threads = 0) {
         clear();
         doc_row.resize(segments.size());
         for (size_t s = 0; s < segments.size(); s++) doc_row[s].assign(segments[s].cord_uid.size(), 0u);
         FileBytes f;
         if (!f.load(csv)) return false;
-        const char* p = (const char*)f.bytes().data();
-        const size_t n = f.size();
-        std::unordered_map<std::string, std::vector<std::pair<uint32_t, uint32_t>>> wanted;
-        wanted.reserve(1024);
-        for (uint32_t s = 0; s < segments.size(); s++)
-            for (uint32_t d = 0; d < segments[s].cord_uid.size(); d++) wanted[segments[s].cord_uid[d]].push_back({s, d});
-        size_t pos = 0;
-        auto next_line = [&](const char*& lp, size_t& ln) -> bool {   // std::getline semantics
-            if (pos >= n) return false;
-            size_t e = pos;
-            while (e < n && p[e] != '\n') e++;
-            lp = p + pos; ln = e - pos;
-            pos = (e < n) ? e + 1 : n;
-            return true;
-        };
-        const char* lp; size_t ln;
-        if (!next_line(lp, ln)) return false;
-        std::vector<std::string> cols, r;
-        csv_split(lp, ln, cols);
-        int uid_i = -1, url_i = -1, pub_i = -1, auth_i = -1, title_i = -1;
-        for (int i = 0; i < (int)cols.size(); i++) {
-            if (cols[i] == "cord_uid") uid_i = i;
-            if (cols[i] == "url") url_i = i;
-            if (cols[i] == "publish_time") pub_i = i;
-            if (cols[i] == "authors") auth_i = i;
-            if (cols[i] == "title") title_i = i;
-        }
-        if (uid_i < 0) return false;
-        std::unordered_map<std::string, bool> seen;   // first occurrence of a cord_uid wins, wanted or not
-        while (next_line(lp, ln)) {
-            rows_in_file++;
-            csv_split(lp, ln, r);
-            if ((int)r.size() <= uid_i) continue;
-            const std::string& uid = r[uid_i];
-            if (uid.empty()) continue;
-            auto w = wanted.find(uid);
-            if (w == wanted.end()) continue;           // not a loaded document: nothing to keep
-            if (!seen.emplace(uid, true).second) continue;
-            MetaFields m;
-            if (title_i >= 0 && (int)r.size() > title_i) m.title = r[title_i];
-            if (url_i >= 0 && (int)r.size() > url_i) {
-                m.url = r[url_i];
-                const size_t semi = m.url.find(';');
-                if (semi != std::string::npos) m.url.resize(semi);
+        const std::string_view text((const char*)f.bytes().data(), f.size());
+        if (text.empty()) return false;                      // std::getline of the header fails
+        // header line
+        size_t body = text.find('\n');
+        const std::string_view head = text.substr(0, body);
+        body = (body == std::string_view::npos) ? text.size() : body + 1;
+        struct Cols { int uid = -1, url = -1, pub = -1, auth = -1, title = -1; } col;
+        {
+            CsvRecord h;
+            h.parse(head);
+            for (size_t i = 0; i < h.size(); i++) {          // the LAST column of a name wins
+                const std::string_view name = h[i];
+                if (name == "cord_uid") col.uid = (int)i;
+                else if (name == "url") col.url = (int)i;
+                else if (name == "publish_time") col.pub = (int)i;
+                else if (name == "authors") col.auth = (int)i;
+                else if (name == "title") col.title = (int)i;
             }
-            if (pub_i >= 0 && (int)r.size() > pub_i) m.publish_time = r[pub_i];
-            if (auth_i >= 0 && (int)r.size() > auth_i) m.author = first_author_et_al(r[auth_i]);
-            rows_.push_back(std::move(m));
-            const uint32_t idx = (uint32_t)rows_.size() - 1;
-            for (auto& sd : w->second) doc_row[sd.first][sd.second] = idx;
-            rows_loaded++;
+        }
+        if (col.uid < 0) return false;
+        // cord_uid -> every (segment, docId) that carries it
+        std::unordered_map<std::string_view, std::vector<std::pair<uint32_t, uint32_t>>> wanted;
+        {
+            size_t n_docs = 0;
+            for (const auto& sg : segments) n_docs += sg.cord_uid.size();
+            wanted.reserve(n_docs);
+            for (uint32_t s = 0; s < segments.size(); s++)
+                for (uint32_t d = 0; d < segments[s].cord_uid.size(); d++) wanted[segments[s].cord_uid[d]].push_back({s, d});
+        }
+        // slices [cutp[i], cutp[i+1]) of the body, each starting right after a '\n'
+        unsigned nt = max_threads ? max_threads : std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+        size_t min_slice = 4u << 20;                         // below ~4 MB per thread the spawn costs more than it saves
+        if (const char* e = std::getenv("NS_META_SLICE_BYTES")) min_slice = std::max<size_t>(1, std::strtoull(e, nullptr, 10));   // tests: many slices of a small file
+        nt = (unsigned)std::max<size_t>(1, std::min<size_t>(nt, (text.size() - body) / min_slice));
+        std::vector<size_t> cutp(nt + 1, text.size());
+        cutp[0] = body;
+        for (unsigned i = 1; i < nt; i++) {
+            size_t at = body + (text.size() - body) / nt * i;
+            at = std::max(at, cutp[i - 1]);
+            const size_t nl = text.find('\n', at);
+            cutp[i] = (nl == std::string_view::npos) ? text.size() : nl + 1;
+        }
+        struct Row { std::string_view uid; MetaFields m; };
+        struct Slice { std::vector<Row> rows; size_t lines = 0; };
+        std::vector<Slice> slices(nt);
+        auto parse_slice = [&](unsigned i) {
+            Slice& out = slices[i];
+            CsvRecord rec;
+            size_t pos = cutp[i];
+            const size_t stop = cutp[i + 1];
+            while (pos < stop) {                             // std::getline: a last line without '\n' still counts
+                size_t e = text.find('\n', pos);
+                if (e == std::string_view::npos || e > stop) e = stop;
+                const std::string_view line = text.substr(pos, e - pos);
+                pos = e + 1;
+                out.lines++;
+                rec.parse(line);
+                const std::string_view uid = rec.at(col.uid);
+                if (uid.empty()) continue;                   // short row, or an empty cord_uid
+                const auto w = wanted.find(uid);
+                if (w == wanted.end()) continue;             // not a loaded document: nothing to keep
+                Row r;
+                r.uid = w->first;                            // the segment's own copy outlives `rec`
+                r.m.title = std::string(rec.at(col.title));
+                const std::string_view url = rec.at(col.url);
+                r.m.url = std::string(url.substr(0, url.find(';')));   // src/api_engine.cpp:525-527
+                r.m.publish_time = std::string(rec.at(col.pub));
+                r.m.author = first_author_et_al(rec.at(col.auth));
+                out.rows.push_back(std::move(r));
+            }
+        };
+        if (nt == 1) {
+            parse_slice(0);
+        } else {
+            std::vector<std::thread> pool;
+            for (unsigned i = 0; i < nt; i++) pool.emplace_back(parse_slice, i);
+            for (auto& t : pool) t.join();
+        }
+        std::unordered_set<std::string_view> taken;          // a cord_uid's first row (in file order) wins
+        for (Slice& sl : slices) {
+            rows_in_file += sl.lines;
+            for (Row& r : sl.rows) {
+                if (!taken.insert(r.uid).second) continue;
+                rows_.push_back(std::move(r.m));
+                const uint32_t idx = (uint32_t)rows_.size() - 1;
+                for (const auto& sd : wanted.find(r.uid)->second) doc_row[sd.first][sd.second] = idx;
+                rows_loaded++;
+            }
         }
         return true;
     }

@@ -16,11 +16,14 @@
 #pragma once
 
 #include <algorithm>
+#include <cerrno>
 #include <cmath>
+#include <cstdlib>
 #include <cstdint>
 #include <fstream>
 #include <sstream>
 #include <string>
+#include <string_view>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -31,6 +34,65 @@
 namespace nsx {
 
 using WeightedTerms = std::vector<std::pair<std::string, float>>;
+
+// Reads numbers and words off a span of text the way the stream extractors the reference uses do in the "C" locale:
+// leading white space is skipped, then the longest prefix the type's grammar admits is taken and converted; a failed
+// extraction ends the sequence (the reference's `while (iss >> x)`).
+struct TextCursor {
+    const char* p;
+    const char* end;
+    static bool blank(char c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
+    static bool digit(char c) { return c >= '0' && c <= '9'; }
+    void skip_blanks() { while (p < end && blank(*p)) p++; }
+    bool only_blanks_left() { skip_blanks(); return p == end; }
+    bool token(std::string_view& out) {
+        skip_blanks();
+        const char* b = p;
+        while (p < end && !blank(*p)) p++;
+        out = std::string_view(b, (size_t)(p - b));
+        return p != b;
+    }
+    // [+-]? digits; out-of-range fails (num_get sets failbit)
+    bool integer(long long& out) {
+        skip_blanks();
+        const char* b = p;
+        if (p < end && (*p == '+' || *p == '-')) p++;
+        const char* d = p;
+        while (p < end && digit(*p)) p++;
+        if (p == d) return false;
+        const std::string tmp(b, p);
+        errno = 0;
+        char* stop = nullptr;
+        out = std::strtoll(tmp.c_str(), &stop, 10);
+        return errno != ERANGE && stop && *stop == 0;
+    }
+    // libstdc++'s float grammar: [+-]? then digits with at most one '.', then — only after a digit — one e/E with an
+    // optional sign, then digits.  The prefix goes through strtof; unconverted characters or +-HUGE_VALF fail.
+    bool real(float& out) {
+        skip_blanks();
+        const char* b = p;
+        if (p < end && (*p == '+' || *p == '-')) p++;
+        bool mantissa = false, point = false, expo = false;
+        for (; p < end; p++) {
+            const char c = *p;
+            if (digit(c)) { mantissa = true; continue; }
+            if (c == '.' && !point && !expo) { point = true; continue; }
+            if ((c == 'e' || c == 'E') && !expo && mantissa) {
+                expo = true;
+                if (p + 1 < end && (p[1] == '+' || p[1] == '-')) p++;
+                continue;
+            }
+            break;
+        }
+        if (p == b) return false;
+        const std::string tmp(b, p);
+        char* stop = nullptr;
+        const float v = std::strtof(tmp.c_str(), &stop);
+        if (!stop || stop == tmp.c_str() || *stop != 0 || std::isinf(v)) return false;
+        out = v;
+        return true;
+    }
+};
 
 class SemanticTable {
 public:
@@ -47,48 +109,56 @@ public:
 
     void clear() { enabled = false; dim = 0; terms.clear(); vecs.clear(); term_to_row.clear(); }
 
-    static void l2_normalize(std::vector<float>& v) {
-        double ss = 0.0;
-        for (float x : v) ss += (double)x * (double)x;
-        const double n = std::sqrt(ss);
-        if (n <= 0.0) return;
-        for (float& x : v) x = (float)(x / n);
+    // v / |v| with the norm summed in double and each component rounded once from the double quotient
+    // (src/semantic_embedding.cpp:18-24); a zero vector stays as it is.
+    static void to_unit_length(float* v, size_t n) {
+        double sq = 0.0;
+        for (size_t i = 0; i < n; i++) sq += (double)v[i] * (double)v[i];
+        const double len = std::sqrt(sq);
+        if (!(len > 0.0)) return;
+        for (size_t i = 0; i < n; i++) v[i] = (float)((double)v[i] / len);
     }
 
+    // The embeddings text file (src/semantic_embedding.cpp:35-101): per non-empty line a word and its values; an
+    // optional first line "<count> <dim>" (two positive integers, dim < 5000, nothing else) is a header.  Kept: words in
+    // `needed` (all words when `needed` is empty) with >= 10 values and the dimension of the first kept line; a
+    // repeated word gets a row of its own but resolves by name to its first row.  The reference reads the lines with
+    // stream extraction; TextCursor below applies the same extraction rules to the file's bytes in place.
     bool load_from_text(const fs::path& path, const std::unordered_set<std::string>& needed) {
         clear();
-        std::ifstream in(path);
-        if (!in.is_open()) return false;
-        std::string line;
-        bool first = true;
-        size_t loaded = 0;
-        while (std::getline(in, line)) {
-            if (line.empty()) continue;
-            if (first) {                                  // optional "<vocab> <dim>" header (:52-59, :66-69)
-                first = false;
-                std::istringstream h(line);
-                long long a, b;
-                std::string extra;
-                if ((h >> a >> b) && !(h >> extra) && a > 0 && b > 0 && b < 5000) continue;
+        FileBytes file;
+        if (!fs::exists(path) || !file.load(path)) return false;
+        const std::string_view text((const char*)file.bytes().data(), file.size());
+        std::vector<float> row;
+        std::string word;
+        bool header_possible = true;
+        for (size_t pos = 0; pos < text.size();) {
+            size_t eol = text.find('\n', pos);
+            if (eol == std::string_view::npos) eol = text.size();
+            TextCursor line{text.data() + pos, text.data() + eol};
+            pos = eol + 1;
+            if (line.p == line.end) continue;                       // empty line: not even a header candidate
+            if (header_possible) {
+                header_possible = false;
+                TextCursor h = line;
+                long long count = 0, width = 0;
+                if (h.integer(count) && h.integer(width) && h.only_blanks_left() && count > 0 && width > 0 && width < 5000) continue;
             }
-            std::istringstream iss(line);
-            std::string word;
-            if (!(iss >> word)) continue;
-            if (!needed.empty() && needed.find(word) == needed.end()) continue;
-            std::vector<float> v;
-            float x;
-            while (iss >> x) v.push_back(x);
-            if (v.size() < 10) continue;
-            if (dim == 0) dim = (int)v.size();
-            if ((int)v.size() != dim) continue;
-            l2_normalize(v);
-            const uint32_t row = (uint32_t)terms.size();
+            std::string_view w;
+            if (!line.token(w)) continue;
+            word.assign(w);
+            if (!needed.empty() && !needed.count(word)) continue;
+            row.clear();
+            for (float x; line.real(x);) row.push_back(x);          // stops at the first thing that is not a number
+            if (row.size() < 10) continue;
+            if (dim == 0) dim = (int)row.size();
+            if ((int)row.size() != dim) continue;
+            to_unit_length(row.data(), row.size());
+            term_to_row.emplace(word, (uint32_t)terms.size());       // emplace: the first row of a word keeps the name
             terms.push_back(word);
-            term_to_row.emplace(word, row);               // a repeated word keeps its FIRST row here, yet gets a new row
-            vecs.insert(vecs.end(), v.begin(), v.end());
-            loaded++;
+            vecs.insert(vecs.end(), row.begin(), row.end());
         }
-        enabled = loaded > 0 && dim > 0;
+        enabled = !terms.empty() && dim > 0;
         return enabled;
     }
 
@@ -126,7 +196,7 @@ public:
             }
             if (global_topk > 0 && cnt > 0) {
                 for (int j = 0; j < dim; j++) cen[(size_t)j] /= (float)cnt;     // :202
-                l2_normalize(cen);
+                to_unit_length(cen.data(), cen.size());
                 c_index[q] = (uint32_t)(c_ban_off.size() - 1);
                 cv.insert(cv.end(), cen.begin(), cen.end());
                 ban_rows_c.insert(ban_rows_c.end(), bl.begin(), bl.end());
@@ -149,26 +219,22 @@ public:
         for (size_t q = 0; q < Q; q++) {
             const auto& qt = qterms[q];
             if (qt.empty()) continue;
+            // weights by term; the ORDER of first insertion decides the map's iteration order, hence the scoring order
             std::unordered_map<std::string, float> w;
             w.reserve((size_t)max_total_terms * 2);
-            for (const auto& t : qt) if (!t.empty()) w[t] = 1.0f;
-            if (per_term > 0)
-                for (uint32_t i = t_first[q]; i < t_first[q + 1]; i++)
-                    for (uint32_t j = 0; j < t_cnt[i]; j++) {
-                        const std::string& cand = terms[t_rows[(size_t)i * per_term + j]];
-                        const float weight = std::max(0.0f, std::min(alpha, alpha * t_sims[(size_t)i * per_term + j]));
-                        auto it = w.find(cand);
-                        if (it == w.end() || weight > it->second) w[cand] = weight;
-                    }
-            if (c_index[q] != 0xFFFFFFFFu) {
-                const uint32_t i = c_index[q];
-                for (uint32_t j = 0; j < c_cnt[i]; j++) {
-                    const std::string& cand = terms[c_rows[(size_t)i * global_topk + j]];
-                    const float weight = std::max(0.0f, std::min(alpha * 0.8f, alpha * 0.8f * c_sims[(size_t)i * global_topk + j]));
-                    auto it = w.find(cand);
-                    if (it == w.end() || weight > it->second) w[cand] = weight;
+            for (const auto& t : qt) if (!t.empty()) w[t] = 1.0f;                    // the query's own terms (:160)
+            // a neighbour weighs cap * sim, at most cap, never negative, and keeps the largest weight it was offered (:186-188, :213-215)
+            auto offer = [&](const uint32_t* rows, const float* sims, uint32_t n, float cap) {
+                for (uint32_t j = 0; j < n; j++) {
+                    const float weight = std::max(0.0f, std::min(cap, cap * sims[j]));
+                    const auto [slot, fresh] = w.try_emplace(terms[rows[j]], weight);
+                    if (!fresh && weight > slot->second) slot->second = weight;
                 }
-            }
+            };
+            for (uint32_t i = t_first[q]; per_term > 0 && i < t_first[q + 1]; i++)
+                offer(&t_rows[(size_t)i * per_term], &t_sims[(size_t)i * per_term], t_cnt[i], alpha);
+            if (const uint32_t i = c_index[q]; i != 0xFFFFFFFFu)
+                offer(&c_rows[(size_t)i * global_topk], &c_sims[(size_t)i * global_topk], c_cnt[i], alpha * 0.8f);
             WeightedTerms& o = out[q];
             o.reserve(w.size());
             for (auto& kv : w) o.push_back(kv);

@@ -52,19 +52,19 @@ assert QDESC_DTYPE.itemsize == C.sizeof(NsQueryDesc) == 8
 # every symbol include/nextsearch_hip.h declares
 HIP_SYMBOLS = [
     "ns_ctx_create", "ns_ctx_destroy", "ns_ctx_set_stream", "ns_last_error", "ns_device_name",
-    "ns_segment_upload", "ns_segment_release", "ns_search_batch", "ns_batch_prepare",
+    "ns_segment_upload", "ns_segment_release", "ns_segment_upload_begin", "ns_segment_upload_append", "ns_segment_upload_end", "ns_search_batch", "ns_batch_prepare",
     "ns_batch_bind_outputs", "ns_batch_run", "ns_batch_sync", "ns_batch_fetch", "ns_batch_get_info",
     "ns_batch_destroy", "ns_set_tuning", "ns_segment_build_impacts", "ns_ctx_use_impacts",
     "ns_invert_forward", "ns_merge_rank_rows", "ns_sem_upload", "ns_sem_release", "ns_sem_topk",
 ]
 HOST_SYMBOLS = [
-    "nsh_gen_index", "nsh_engine_open", "nsh_engine_close", "nsh_engine_error", "nsh_engine_ctx",
+    "nsh_gen_index", "nsh_engine_open", "nsh_engine_close", "nsh_engine_reload", "nsh_engine_error", "nsh_engine_ctx",
     "nsh_engine_num_segments", "nsh_engine_segment_name", "nsh_engine_segment_info",
     "nsh_engine_segment_doc_len", "nsh_engine_segment_postings", "nsh_engine_lookup", "nsh_bm25_idf",
     "nsh_base_terms", "nsh_engine_build_refs", "nsh_engine_search_json", "nsh_free",
     "nsh_engine_search_batch", "nsh_engine_prepare", "nsh_engine_doc_metadata", "nsh_engine_hits_to_json", "nsh_engine_search_batch_json",
     "nsh_engine_build_impacts", "nsh_engine_use_impacts", "nsh_invert_segment", "nsh_invert_error",
-    "nsh_engine_semantic_info", "nsh_engine_expand", "nsh_engine_set_cache", "nsh_engine_cache_size",
+    "nsh_engine_semantic_info", "nsh_engine_expand", "nsh_engine_semantic_row", "nsh_engine_set_cache", "nsh_engine_cache_size",
 ]
 
 _hip = None
@@ -89,6 +89,9 @@ def hip_lib():
         L.ns_device_name.restype = C.c_char_p
         L.ns_segment_upload.argtypes = [vp, u32, u32, C.c_float, vp, vp, u64, C.POINTER(vp)]
         L.ns_segment_release.argtypes = [vp, vp]
+        L.ns_segment_upload_begin.argtypes = [vp, u32, u32, C.c_float, vp, u64, C.POINTER(vp)]
+        L.ns_segment_upload_append.argtypes = [vp, vp, vp, u64]
+        L.ns_segment_upload_end.argtypes = [vp, vp]
         L.ns_segment_build_impacts.argtypes = [vp, vp, vp, vp, vp, u32]
         L.ns_ctx_use_impacts.argtypes = [vp, i32]
         L.ns_sem_upload.argtypes = [vp, vp, u32, u32, C.POINTER(vp)]
@@ -122,6 +125,7 @@ def host_lib():
         L.nsh_engine_open.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
         L.nsh_engine_close.argtypes = [vp]
         L.nsh_engine_close.restype = None
+        L.nsh_engine_reload.argtypes = [vp]
         L.nsh_engine_error.argtypes = [vp]
         L.nsh_engine_error.restype = C.c_char_p
         L.nsh_engine_ctx.argtypes = [vp]
@@ -159,6 +163,7 @@ def host_lib():
         L.nsh_engine_cache_size.restype = u32
         L.nsh_engine_semantic_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
         L.nsh_engine_expand.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
+        L.nsh_engine_semantic_row.argtypes = [vp, u32, C.POINTER(C.c_char_p), C.POINTER(vp)]
         L.nsh_engine_build_impacts.argtypes = [vp]
         L.nsh_engine_use_impacts.argtypes = [vp, i32]
         L.nsh_engine_use_impacts.restype = None
@@ -255,6 +260,11 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+    def reload(self):
+        """Engine::reload() on the same directory; on failure the engine keeps what it had."""
+        if self._L.nsh_engine_reload(self.h) != 0:
+            raise RuntimeError(f"Engine.reload failed: {self.error()}")
 
     def error(self):
         return self._L.nsh_engine_error(self.h).decode()
@@ -380,6 +390,14 @@ class Engine:
         rows, dim = C.c_uint32(), C.c_uint32()
         on = self._L.nsh_engine_semantic_info(self.h, C.byref(rows), C.byref(dim))
         return bool(on), rows.value, dim.value
+
+    def semantic_row(self, row):
+        """(term, fp32 vector) of one row of the loaded embedding table."""
+        _, _, dim = self.semantic_info()
+        t, v = C.c_char_p(), C.c_void_p()
+        if self._L.nsh_engine_semantic_row(self.h, row, C.byref(t), C.byref(v)) != 0:
+            raise IndexError(row)
+        return t.value.decode(), np.ctypeslib.as_array(C.cast(v, C.POINTER(C.c_float)), shape=(dim,)).copy()
 
     def expand(self, query):
         """[(term, fp32 weight bits)] a search scores for this query, in scoring order."""

@@ -52,7 +52,7 @@ static void drop_cache(cord19::Engine& e) {
 
 int main(int argc, char** argv) {
     if (argc < 6) {
-        std::fprintf(stderr, "usage: %s search|json|expand|time <index_dir> <queries.txt> <K> <out|max_seconds>\n", argv[0]);
+        std::fprintf(stderr, "usage: %s search|json|expand|semtable|time <index_dir> <queries.txt> <K> <out|max_seconds>\n", argv[0]);
         return 2;
     }
     std::string mode = argv[1];
@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
     std::string qpath = fs::absolute(argv[3]).string();
     int K = std::atoi(argv[4]);
     std::string last = argv[5];
-    std::string outpath = (mode == "search" || mode == "json" || mode == "json2" || mode == "expand") ? fs::absolute(last).string() : std::string();
+    std::string outpath = (mode == "search" || mode == "json" || mode == "json2" || mode == "expand" || mode == "semtable") ? fs::absolute(last).string() : std::string();
 
     auto queries = read_lines(qpath);
 
@@ -147,6 +147,22 @@ int main(int argc, char** argv) {
                     std::memcpy(&bits, &tw.second, 4);
                     std::fprintf(out, "%s\t%08x\n", tw.first.c_str(), bits);
                 }
+            }
+            std::fclose(out);
+        } else if (mode == "semtable") {
+            // the embedding table as SemanticIndex::load_from_text left it (src/semantic_embedding.cpp:35-101): per row the
+            // term and the fp32 bits of its normalised vector
+            std::FILE* out = std::fopen(outpath.c_str(), "w");
+            if (!out) { std::perror("out"); return 1; }
+            std::fprintf(out, "S %d %zu %d\n", engine.sem.enabled ? 1 : 0, engine.sem.terms.size(), engine.sem.dim);
+            for (size_t r = 0; r < engine.sem.terms.size(); r++) {
+                std::fprintf(out, "%s", engine.sem.terms[r].c_str());
+                for (int j = 0; j < engine.sem.dim; j++) {
+                    uint32_t bits;
+                    std::memcpy(&bits, &engine.sem.vecs[r * (size_t)engine.sem.dim + j], 4);
+                    std::fprintf(out, " %08x", bits);
+                }
+                std::fprintf(out, "\n");
             }
             std::fclose(out);
         } else if (mode == "time") {

@@ -218,11 +218,15 @@ def test_result_assembly_equals_reference_json_text(tmp_path_factory):
     eng.close()
 
 
-def test_metadata_table_equals_python_restatement(tmp_path_factory):
+@pytest.mark.parametrize("slice_bytes", [0, 40_000, 977])
+def test_metadata_table_equals_python_restatement(tmp_path_factory, monkeypatch, slice_bytes):
     """Every document's decorated fields against an independent restatement of src/api_metadata.cpp's rules
     (physical lines, quote toggling without escapes, last header column wins, first row per cord_uid wins,
-    url cut at ';', first_author_et_al)."""
+    url cut at ';', first_author_et_al).  slice_bytes > 0 forces the loader's several-threads path on the small
+    fixture (slices cut at line ends, merged in file order: duplicates of a cord_uid may sit in different slices)."""
     g, d, csv = _meta_index(tmp_path_factory)
+    if slice_bytes:
+        monkeypatch.setenv("NS_META_SLICE_BYTES", str(slice_bytes))
 
     def split(line):
         out, cur, inq = [], [], False
@@ -323,6 +327,106 @@ def test_search_cache_holds_only_answers():
         assert eng.cache_size() == 0
     finally:
         eng.close()
+
+
+def test_engine_entries_are_serialised_like_the_reference():
+    """The reference takes Engine::mtx in every entry (src/api_engine.cpp:54,:168,:372) because its HTTP layer calls
+    search() from a thread pool.  Host-only engine: eight threads hammer search (fails: no device, must not corrupt the
+    cache or the error string), query preparation and the cache switch at once; results must equal the serial ones."""
+    import tempfile
+    import threading
+    d = tempfile.mkdtemp(prefix="ns_mt_")
+    idx = os.path.join(d, "i")
+    nsbind.gen_index(idx, 2, 400, 128, 5, False)
+    eng = nsbind.Engine(idx, -1)
+    try:
+        queries = ["covid virus", "vaccine t000020", "zzzz", "the of", "patients covid covid"] * 40
+        serial = eng.build_refs(queries)
+        errors = []
+
+        def worker(i):
+            try:
+                for it in range(30):
+                    if i % 3 == 0:
+                        try:
+                            eng.search_json(queries[(i + it) % len(queries)], 10)
+                            errors.append("search without a device succeeded")
+                        except RuntimeError as ex:
+                            if "no device" not in str(ex):
+                                errors.append(str(ex))
+                    elif i % 3 == 1:
+                        qd, refs, usable = eng.build_refs(queries)
+                        if qd.tobytes() != serial[0].tobytes() or refs.tobytes() != serial[1].tobytes() or usable.tobytes() != serial[2].tobytes():
+                            errors.append("build_refs differs under concurrency")
+                    else:
+                        eng.set_cache(it % 2 == 0)
+                        eng.cache_size()
+            except Exception as ex:   # noqa: BLE001
+                errors.append(repr(ex))
+
+        th = [threading.Thread(target=worker, args=(i,)) for i in range(8)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errors, errors[:3]
+        assert eng.cache_size() == 0
+    finally:
+        eng.close()
+
+
+def test_failed_reload_keeps_the_loaded_index_and_corrupt_files_fail_cleanly():
+    """The reference swaps its segments in only after every one loaded (src/api_engine.cpp:76-90).  A reload that fails
+    half way must leave the engine as it was; corrupt counts in docs.bin / manifest.bin / barrels.bin must end in an
+    error return, not in an exception or an allocation of the claimed size crossing the C boundary."""
+    import shutil
+    import struct
+    import tempfile
+    d = tempfile.mkdtemp(prefix="ns_reload_")
+    idx = os.path.join(d, "i")
+    nsbind.gen_index(idx, 2, 300, 64, 9, False)
+    eng = nsbind.Engine(idx, -1)
+    try:
+        before = eng.build_refs(["covid virus", "vaccine"])
+        info = eng.segment_info(1)
+        seg2 = os.path.join(idx, "segments", "seg_000002")
+        shutil.move(os.path.join(seg2, "stats.bin"), os.path.join(d, "stats.keep"))
+        with pytest.raises(RuntimeError, match="failed to load segment"):
+            eng.reload()
+        assert eng.num_segments == 2 and eng.segment_info(1) == info
+        after = eng.build_refs(["covid virus", "vaccine"])
+        assert all(a.tobytes() == b.tobytes() for a, b in zip(before, after))
+        shutil.move(os.path.join(d, "stats.keep"), os.path.join(seg2, "stats.bin"))
+        # docs.bin claiming 2^32 - 1 documents
+        docs = os.path.join(seg2, "docs.bin")
+        raw = open(docs, "rb").read()
+        open(docs, "wb").write(struct.pack("<I", 0xFFFFFFFF) + raw[4:])
+        with pytest.raises(RuntimeError, match="failed to load segment"):
+            eng.reload()
+        open(docs, "wb").write(raw)
+        # barrels.bin claiming 2^31 barrels
+        bpath = os.path.join(seg2, "barrels.bin")
+        braw = open(bpath, "rb").read()
+        open(bpath, "wb").write(struct.pack("<II", 1 << 31, 1))
+        with pytest.raises(RuntimeError, match="failed to load segment"):
+            eng.reload()
+        open(bpath, "wb").write(braw)
+        eng.reload()                                             # everything restored: loads again
+        assert eng.num_segments == 2 and eng.segment_info(1) == info
+        # a manifest with a corrupt count: no usable names -> falls back to scanning segments/ (src/api_engine.cpp:57-73)
+        mpath = os.path.join(idx, "manifest.bin")
+        mraw = open(mpath, "rb").read()
+        open(mpath, "wb").write(struct.pack("<I", 0xFFFFFFF0) + mraw[4:])
+        eng.reload()
+        assert eng.num_segments == 2
+        # raw postings are read on request only and equal the files
+        p0 = eng.segment_postings(0)
+        files = sorted(f for f in os.listdir(os.path.join(idx, "segments", "seg_000001")) if f.startswith("inverted_b"))
+        cat = b"".join(open(os.path.join(idx, "segments", "seg_000001", f), "rb").read() for f in files)
+        assert p0.tobytes() == cat
+    finally:
+        eng.close()
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def test_tools_and_entry_points_compile():

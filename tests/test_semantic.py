@@ -123,6 +123,32 @@ def test_embedding_loader_equals_reference(index_factory):
         os.remove(path)
 
 
+def test_embedding_loader_bits_equal_reference_on_odd_spellings(index_factory):
+    """tests/golden/semload1.json: an embeddings file full of spellings that tell number readers apart (glued
+    numbers, bare points, dangling exponents, over- and underflow, text inside a line, CR ends, a header look-alike,
+    a last line without newline) and the table the REAL reference's load_from_text made of it — rows, names and the
+    fp32 bits of every normalised value.  This repo's loader (own scanner, no streams) must produce the same table."""
+    import base64
+    from conftest import load_golden
+    g = load_golden("semload1")
+    p = g["params"]
+    d, _ = index_factory(p["n_segments"], p["docs_per_segment"], p["vocab"], p["seed"], p["legacy"])
+    path = os.path.join(d, "embeddings.vec")
+    with open(path, "wb") as f:
+        f.write(base64.b64decode(g["embeddings_b64"]))
+    try:
+        eng = nsbind.Engine(d, -1)
+        on, rows, dim = eng.semantic_info()
+        assert (int(on), rows, dim) == (g["enabled"], len(g["table"]), g["dim"])
+        for r, (term, bits) in enumerate(g["table"]):
+            t, v = eng.semantic_row(r)
+            assert t == term
+            assert v.view(np.uint32).tolist() == bits, (r, term)
+        eng.close()
+    finally:
+        os.remove(path)
+
+
 @pytest.mark.gpu
 def test_semantic_search_equals_reference(index_factory):
     g, d, path = _sem_fixture(index_factory)

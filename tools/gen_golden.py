@@ -7,6 +7,7 @@ texts and the reference's outputs (found, and per hit: segment index, docId, fp3
 
     python tools/gen_golden.py
 """
+import base64
 import hashlib
 import json
 import os
@@ -206,6 +207,70 @@ def make_sem_fixture(outdir):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+SEMLOAD_PARAMS = dict(n_segments=1, docs_per_segment=300, vocab=48, seed=7, legacy=False)
+
+
+def semload_text():
+    """A small embeddings file full of the spellings that tell one number reader from another (the reference reads the
+    values with operator>>(float)): signs, bare points, exponents, numbers glued together, text in the middle of a
+    line, a header look-alike that is not the first line, CR line ends, a repeated word, an all-zero vector."""
+    T = workloads.term_name
+    base = ["0.5", "-0.25", "1", "2.5e-1", "-3E+0", ".75", "4.", "+0.125", "1e1", "0.001", "7", "-8.5"]
+    L = []
+    L.append("  48   12  ")                                      # header (blanks around it)
+    L.append(T(1) + " " + " ".join(base))
+    L.append(T(2) + "\t" + "\t".join(reversed(base)) + "\r")    # tabs, CR at the end
+    L.append("")
+    L.append(T(3) + " 1 2 3 4 5 6 7 8 9 10 11 abc 12")           # stops at abc: 11 values -> another dimension, skipped
+    L.append(T(4) + " 1 2 3 4 5 6 7 8 9 10 11 12 xyz 13")        # stops at xyz: 12 values, kept
+    L.append(T(5) + " 1.5-3 2 3 4 5 6 7 8 9 10 11")              # "1.5-3" reads as 1.5 then -3: 12 values
+    L.append(T(6) + " 1e 2 3 4 5 6 7 8 9 10 11 12")              # "1e" is not a number: no values at all
+    L.append(T(7) + " 1e+ 2 3 4 5 6 7 8 9 10 11 12")
+    L.append(T(8) + " . 2 3 4 5 6 7 8 9 10 11 12")
+    L.append(T(9) + " 0 0 0 0 0 0 0 0 0 0 0 0")                  # zero vector: stays zero
+    L.append(T(10) + " 1e39 2 3 4 5 6 7 8 9 10 11 12")           # overflows a float: extraction fails
+    L.append(T(11) + " 1e-46 2 3 4 5 6 7 8 9 10 11 12")          # underflows to zero: fine
+    L.append(T(12) + " 0x10 2 3 4 5 6 7 8 9 10 11 12")           # "0" then "x10" stops
+    L.append(T(13) + " 1,5 2 3 4 5 6 7 8 9 10 11 12")
+    L.append(T(14) + " inf 2 3 4 5 6 7 8 9 10 11 12")
+    L.append(T(15) + " 00012.50 -0 +.5e1 1.e2 1.5E-2 3 4 5 6 7 8 9")
+    L.append("12 12")                                            # looks like a header, but is not the first line
+    L.append(T(1) + " 9 8 7 6 5 4 3 2 1 0 1 2")                  # repeated word: a new row, the name keeps its first row
+    L.append("notinlexicon 1 2 3 4 5 6 7 8 9 10 11 12")
+    L.append(T(16) + " 1 2 3 4 5 6 7 8 9")                       # < 10 values
+    L.append(T(17) + " 1..2 2 3 4 5 6 7 8 9 10 11 12")           # "1." then ".2"
+    L.append(T(18) + " 1e5e2 2 3 4 5 6 7 8 9 10 11 12")
+    L.append(T(19) + " -+1 2 3 4 5 6 7 8 9 10 11 12")
+    L.append(T(20) + " 3.4028235e38 -3.4028235e38 1.17549435e-38 16777217 0.1 0.2 0.3 0.7 1e-7 123456789 5 6")
+    return ("\n".join(L) + "\n" + T(21) + " 12 11 10 9 8 7 6 5 4 3 2 1").encode()   # last line without a newline
+
+
+def make_semload_fixture(outdir):
+    """What the REAL reference's SemanticIndex::load_from_text makes of semload_text(): rows, names, fp32 bits."""
+    import subprocess
+    p = SEMLOAD_PARAMS
+    tmp = tempfile.mkdtemp(prefix="ns_golden_semload_")
+    try:
+        idx = os.path.join(tmp, "index")
+        nsbind.gen_index(idx, p["n_segments"], p["docs_per_segment"], p["vocab"], p["seed"], p["legacy"])
+        emb = semload_text()
+        with open(os.path.join(idx, "embeddings.vec"), "wb") as f:
+            f.write(emb)
+        qpath, opath = os.path.join(tmp, "q.txt"), os.path.join(tmp, "t.txt")
+        open(qpath, "w").write("covid\n")
+        subprocess.check_call([orc.REF_DRIVER, "semtable", idx, qpath, "10", opath], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        lines = open(opath).read().split("\n")
+        _, enabled, rows, dim = lines[0].split()
+        table = [[ln.split(" ")[0], [int(x, 16) for x in ln.split(" ")[1:]]] for ln in lines[1:1 + int(rows)]]
+        with open(os.path.join(outdir, "semload1.json"), "w") as f:
+            json.dump({"name": "semload1", "params": p, "embeddings_b64": base64.b64encode(emb).decode(), "enabled": int(enabled), "dim": int(dim), "table": table,
+                       "source": "cord19::SemanticIndex::load_from_text of /root/reference (through Engine::reload), dumped by oracle/_ref/ref_driver semtable"},
+                      f, separators=(",", ":"))
+        print("semload1: rows", rows, "dim", dim, "bytes", os.path.getsize(os.path.join(outdir, "semload1.json")))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def segwriter_spec(n_docs=150, seed=31):
     """Logical documents for the reference's SegmentWriter: cord_uid, title, json_relpath, doc_len, term:tf ..."""
     rng = random.Random(seed)
@@ -289,6 +354,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "segwriter":
         make_segwriter_fixture(os.path.join(ROOT, "tests", "golden"))
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "semload":
+        make_semload_fixture(os.path.join(ROOT, "tests", "golden"))
         return
     if len(sys.argv) > 1 and sys.argv[1] == "sem":
         make_sem_fixture(os.path.join(ROOT, "tests", "golden"))
