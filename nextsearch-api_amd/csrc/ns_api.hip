@@ -113,7 +113,7 @@ static int fail(ns_ctx* ctx, int code, const char* fmt, ...) {
     } while (0)
 
 // Kernel variants (DESIGN.md "kernel variants").
-//   wave variants (k_wscore): hb = accumulator-table entries per wave (batch = hb/2 postings)
+//   wave variants: hb = table entries per wave (k_dscore) or docs per tile (k_tscore)
 //   workgroup variants (k_score, the >64-terms fallback and the round-1 baseline): threads per
 //   workgroup, slots per thread, postings per thread per round; tile_docs = nt * spt.
 struct VariantDesc { uint32_t hb; uint32_t nt, spt, u; uint32_t d; };
@@ -123,13 +123,8 @@ static const VariantDesc kVariants[] = {
     {0, 512, 12, 4, 0},         // 2: workgroup kernel,  6144-doc tiles
     {0, 256, 16, 4, 0},         // 3: workgroup kernel,  4096-doc tiles
     {0, 512, 16, 8, 0},         // 4: workgroup kernel,  8192-doc tiles
-    {256, 512, 12, 4, 256},     // 5: wave kernel, 256 keys / 256 direct slots
-    {512, 512, 12, 4, 512},     // 6: wave kernel, 512 / 512
-    {1024, 512, 12, 4, 1024},   // 7: wave kernel, 1024 / 1024
-    {512, 512, 12, 4, 1024},    // 8: wave kernel, 512 keys / 1024 direct slots
-    {512, 512, 12, 4, 2048},    // 9: wave kernel, 512 keys / 2048 direct slots
-    {256, 512, 12, 4, 1024},    // 10: wave kernel, 256 keys / 1024 direct slots
-    {256, 512, 12, 4, 2048},    // 11: wave kernel, 256 keys / 2048 direct slots
+    {0, 0, 0, 0, 0},            // 5..11: retired in round 2 (the wave-private batch kernel k_wscore); ns_set_tuning rejects them
+    {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0},
     {512, 512, 12, 4, 0},       // 12: driver-stream kernel (k_dscore), 512 slots, 128 foreign postings per super-batch   [d == 0 marks k_dscore]
     {256, 512, 12, 4, 0},       // 13: k_dscore  256 slots /  64 foreign
     {1024, 512, 12, 4, 0},      // 14: k_dscore 1024 slots / 256 foreign
@@ -149,16 +144,6 @@ static constexpr uint32_t kSplitWorkSmallK = 98304, kSplitWorkLargeK = 131072;
 static constexpr uint64_t kWorkForeign = 8, kWorkTile = 2;
 // per-item, per-term constants of the launch-order key (fitted to per-item timestamps, tools/dbg/item_times.py)
 static constexpr uint64_t kItemTermGeneral = 10000, kItemTermThin = 3000, kItemTermTile = 8000;
-
-template <int D, int HK>
-static void launch_wscore(bool and_mode, uint32_t n_items, hipStream_t st, const DevWItem* items, const DevTerm* terms,
-                          const DevSeg* segs, Hit* hits, uint32_t* nhits, uint64_t* found, uint32_t K) {
-    dim3 grid((n_items + 3) / 4), block(256);
-    if (and_mode)
-        hipLaunchKernelGGL((k_wscore<D, HK, true>), grid, block, 0, st, items, n_items, terms, segs, hits, nhits, found, K);
-    else
-        hipLaunchKernelGGL((k_wscore<D, HK, false>), grid, block, 0, st, items, n_items, terms, segs, hits, nhits, found, K);
-}
 
 template <int HK, int FB>
 static void launch_dscore(bool and_mode, uint32_t n_items, hipStream_t st, const DevWItem* items, const DevTerm* terms,
@@ -248,7 +233,7 @@ extern "C" const char* ns_device_name(ns_ctx* ctx) { return ctx ? ctx->devname.c
 
 extern "C" int ns_set_tuning(ns_ctx* ctx, uint32_t variant, uint32_t min_items, uint32_t split_postings) {
     if (!ctx) return fail(nullptr, NS_E_INVAL, "ns_set_tuning: ctx is NULL");
-    if (variant >= kNumVariants) return fail(ctx, NS_E_INVAL, "unknown kernel variant %u", variant);
+    if (variant >= kNumVariants || kVariants[variant].nt == 0) return fail(ctx, NS_E_INVAL, "unknown kernel variant %u", variant);
     ctx->variant = variant;
     ctx->min_items = min_items;
     ctx->split_postings = split_postings;
@@ -640,7 +625,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
     }
 
     // ---- regroup term refs by (query, segment), keeping query-term order inside each group ----
-    struct HostGroup { DevGroup g; uint32_t query; uint64_t cost; uint64_t cmax; uint64_t work; bool wave; uint8_t cls; bool fast_div; };
+    struct HostGroup { DevGroup g; uint32_t query; uint64_t cost; uint64_t cmax; uint64_t work; bool wave; uint8_t cls; bool fast_div; bool signed_in; };
     std::vector<DevTerm> dterms;
     std::vector<HostGroup> groups;
     std::vector<uint32_t> qgroup_begin(n_queries + 1, 0);
@@ -685,6 +670,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                 }
                 // 2^-30 <= idf <= 2^30 (and finite): see ns_div_short
                 if (!(r.idf >= 9.313225746154785e-10f && r.idf <= 1073741824.0f)) hg.fast_div = false;
+                if (std::signbit(r.idf) || std::signbit(r.qweight)) hg.signed_in = true;   // a contribution may be -0.0f (see dscore_body)
             }
             hg.g.term_count = (uint32_t)dterms.size() - hg.g.term_begin;
             if ((flags & NS_FLAG_AND) && hg.g.term_count > 255) return fail(ctx, NS_E_INVAL, "AND mode supports at most 255 term refs per (query, segment)");
@@ -763,7 +749,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                     it.doc_hi = (uint32_t)((uint64_t)sg.n_docs * (i + 1) / ns);
                     if (it.doc_hi <= it.doc_lo) continue;
                     it.out_slot = n_rows++;
-                    it.whole = (ns == 1 ? 1u : 0u) | (hg.fast_div ? 8u : 0u);
+                    it.whole = (ns == 1 ? 1u : 0u) | (hg.fast_div ? 8u : 0u) | (hg.signed_in ? 16u : 0u);
                     {
                         // launch-order key = estimated run time of the ITEM: its share of the group's work plus what
                         // every item pays per term regardless of size (window planning, range searches, table set-up)
@@ -1017,7 +1003,6 @@ extern "C" int ns_batch_run(ns_batch* b, int timed) {
 #undef NS_U
     } else if (b->n_witems) {
         const VariantDesc wv = kVariants[b->variant];
-#define NS_W(DD, HH) launch_wscore<DD, HH>(and_mode, b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K)
 #define NS_D(HH, FF) launch_dscore<HH, FF>(and_mode, b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K)
         if (wv.d == 1) {
             if (wv.hb == 512) launch_tscore<512>(and_mode, b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K);
@@ -1034,14 +1019,6 @@ extern "C" int ns_batch_run(ns_batch* b, int timed) {
             }
         }
 #undef NS_D
-        else if (wv.hb == 256 && wv.d == 256) NS_W(256, 256);
-        else if (wv.hb == 256 && wv.d == 1024) NS_W(1024, 256);
-        else if (wv.hb == 256 && wv.d == 2048) NS_W(2048, 256);
-        else if (wv.hb == 1024) NS_W(1024, 1024);
-        else if (wv.d == 1024) NS_W(1024, 512);
-        else if (wv.d == 2048) NS_W(2048, 512);
-        else NS_W(512, 512);
-#undef NS_W
     }
     if (b->n_items) {
         const VariantDesc vd = kVariants[b->variant];

@@ -15,6 +15,7 @@
 //      is 0.0f + w*s == w*s exactly, it never touches the table; a hit joins the table accumulation
 //   4. accumulate the foreign terms that come AFTER the driver
 //   5. owners read the final scores back, count `found`, offer candidates, reset their slots
+// Accumulators start at +0.0f like the reference's; `found` counts owners and private postings, never values.
 // fp32 accumulation order per doc == query-term order (src/api_engine.cpp:449,480) by construction.
 // A hot list joined with sparse lists therefore runs at streaming speed, with the table touched only
 // by the sparse postings; dense + dense queries degrade gracefully to the table path for the
@@ -54,6 +55,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
     const DevSeg seg = segs[it.seg];
     const uint32_t T = it.term_count;
     const bool fast_div = (__builtin_amdgcn_readfirstlane((int)it.whole) & 8) != 0;   // host: every idf and norm of this item is in the range where v_div_scale/v_div_fixup are the identity
+    const bool signed_in = (__builtin_amdgcn_readfirstlane((int)it.whole) & 16) != 0;   // host: some idf or weight has its sign bit set
     const gp_u2 postings = (gp_u2)seg.postings;
     const gp_f32 pnorm = (gp_f32)seg.pnorm;
     // IMP: every list of this item has its term scores precomputed (same arithmetic, done once per list at
@@ -61,15 +63,12 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
     const gp_u2 stream = IMP ? (gp_u2)seg.impacts : postings;
 
     {
-        const float4 sent4 = make_float4(__uint_as_float(kSentinelBits), __uint_as_float(kSentinelBits),
-                                         __uint_as_float(kSentinelBits), __uint_as_float(kSentinelBits));
         const uint4 empty4 = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
-        (void)sent4;
 #pragma unroll
         for (int g = 0; g < NB / 64; g++) ent4[g * 64 + lane] = empty4;
 #pragma unroll
         for (int g = 0; g < FB / 64; g++) {
-            vals[g * 64 + lane] = __uint_as_float(kSentinelBits);
+            vals[g * 64 + lane] = 0.0f;   // the reference's accumulators start at +0.0f (src/api_engine.cpp:480)
             if (AND) mcnt[g * 64 + lane] = 0;
         }
     }
@@ -359,7 +358,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
         }
 
         // term-ordered accumulation of foreign terms in [ta, tb] (read-add-write per term; docIds are
-        // unique inside a term, so it is race-free; -0.0f is the exact additive identity)
+        // unique inside a term, so it is race-free)
 #define NS_FOREIGN_RMW(ta, tb)                                                                     \
         for (uint32_t tt = (ta); tt <= (tb); tt++) {                                               \
             if (tt == dl) continue;                                                                \
@@ -432,6 +431,13 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
                 }
 #pragma unroll
                 for (int j = 0; j < DE; j++) dx[j] = d_wq * dx[j];
+                // A private posting's doc score is the reference's 0.0f + w*s.  That is w*s itself unless w*s is -0.0f,
+                // which needs a sign bit in idf or weight (a posting with tf == 0 then gives it): rare enough for a
+                // wave-uniform branch around one add per posting.
+                if (signed_in) {
+#pragma unroll
+                    for (int j = 0; j < DE; j++) dx[j] = 0.0f + dx[j];
+                }
             }
             // does any foreign doc of this super-batch fall into the doc range of this round?  (usually
             // not when the driver is much denser than the foreign lists: then the lookups are skipped)
@@ -519,7 +525,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
 #pragma unroll
             for (int j = 0; j < FE; j++) {
                 if (fmine[j]) {   // the owner resets its entry and accumulator for the next super-batch
-                    vals[j * 64 + lane] = __uint_as_float(kSentinelBits);
+                    vals[j * 64 + lane] = 0.0f;
                     ent[ftj[j] >> 14] = EMPTY;
                     if (AND) mcnt[j * 64 + lane] = 0;
                 }

@@ -5,12 +5,15 @@
 
 namespace ns {
 
-// Untouched accumulator slot.  The reference starts every doc's score at +0.0f
-// (unordered_map value-initialisation, src/api_engine.cpp:480).  -0.0f is an exact additive
-// identity for every x != -0.0f under round-to-nearest (-0 + x == x == +0 + x), and stays
-// distinguishable from any touched slot, so "touched" costs no extra LDS state.
-static constexpr uint32_t kSentinelBits = 0x80000000u;
-
+// Accumulators start at +0.0f, as the reference's do (unordered_map value-initialisation, src/api_engine.cpp:480):
+// `0.0f + x` is x for every x except -0.0f, which it turns into +0.0f — the reference never returns a negative zero.
+//
+// The doc-tile body (and k_score, the workgroup-tile fallback for > 64 terms) additionally has to tell an UNTOUCHED slot from a touched one (`found`, :495, counts a doc the
+// first time any term hits it, whatever the contribution's value — a posting with tf == 0 contributes an exact zero).
+// Its empty slots therefore hold a bit pattern no sum can take: an all-ones NaN.  The first posting that meets it
+// counts the doc and starts from +0.0f.  (fp32 arithmetic on finite or infinite inputs never produces this payload;
+// an idf or weight that is itself this NaN is outside what the engine can pass.)
+static constexpr uint32_t kTileEmptyBits = 0xFFFFFFFFu;
 struct DevSeg {
     const uint2* postings;   // {docId, tf} pairs, all inverted files of the segment back to back
     const float* pnorm;      // per POSTING: norm[docId] (streams next to the posting; no dependent gather)
@@ -55,7 +58,9 @@ struct DevWItem {
     uint32_t doc_hi;
     uint32_t out_slot;
     uint32_t whole;        // bit 0: range covers the whole segment (no start/end searches needed); bit 1: doc-tile body;
-                           // bit 2: thin foreign lists; bit 3: idf and norms in the short-division range (ns_div_short)
+                           // bit 2: thin foreign lists; bit 3: idf and norms in the short-division range (ns_div_short);
+                           // bit 4: some idf or weight of the group has its sign bit set (a contribution may be -0.0f: the
+                           //        driver stream then canonicalises its private scores as the reference's 0.0f + x does)
 };
 
 // Term group == the (query, segment) unit the boundary prepass works on.

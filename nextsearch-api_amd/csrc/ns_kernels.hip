@@ -147,8 +147,8 @@ __global__ void __launch_bounds__(NT) k_score(const DevItem* __restrict__ items,
 
     // ---- init LDS ----
     {
-        float4 sent4 = make_float4(__uint_as_float(kSentinelBits), __uint_as_float(kSentinelBits),
-                                   __uint_as_float(kSentinelBits), __uint_as_float(kSentinelBits));
+        float4 sent4 = make_float4(__uint_as_float(kTileEmptyBits), __uint_as_float(kTileEmptyBits),
+                                   __uint_as_float(kTileEmptyBits), __uint_as_float(kTileEmptyBits));
         float4* acc4 = reinterpret_cast<float4*>(acc);
 #pragma unroll
         for (int g = 0; g < NG; g++) acc4[g * NT + tid] = sent4;
@@ -242,9 +242,10 @@ __global__ void __launch_bounds__(NT) k_score(const DevItem* __restrict__ items,
                     float s = (s_idf[tj[j]] * (tf * (1.2f + 1.0f))) / denom;
                     x[j] = s_w[tj[j]] * s;
                 }
-                // ---- ordered accumulation: term t's adds happen after all adds of terms < t.
-                // Terms 0 and 1 commute exactly ((-0 + a) + b == (-0 + b) + a), so the first barrier
-                // is needed before term 2.
+                // ---- ordered accumulation: term t's adds happen after all adds of terms < t (the fp32 order of
+                // src/api_engine.cpp:449,480): a barrier separates the terms, and inside one term every posting has
+                // a doc of its own, so a plain read-add-write is race-free — no LDS float atomics (ds_add_f32 costs
+                // ~3 clk per lane on gfx950, and an atomic could not start an untouched slot from +0.0f).
                 uint32_t t_first, t_last;
                 {
                     uint32_t pe = min(base + (uint32_t)(NT * U), L) - 1;
@@ -256,11 +257,12 @@ __global__ void __launch_bounds__(NT) k_score(const DevItem* __restrict__ items,
                     t_last = a;
                 }
                 for (uint32_t tt = t_first; tt <= t_last; tt++) {
-                    if (tg + tt >= 2) __syncthreads();
+                    __syncthreads();
 #pragma unroll
                     for (int j = 0; j < U; j++) {
                         if (valid[j] && tj[j] == tt) {
-                            atomicAdd(&acc[slot[j]], x[j]);   // ds_add_f32, no return
+                            const float old = acc[slot[j]];
+                            acc[slot[j]] = ((__float_as_uint(old) == kTileEmptyBits) ? 0.0f : old) + x[j];   // an untouched slot starts at the reference's +0.0f
                             if (AND) atomicAdd(&mcnt[slot[j] >> 2], 1u << ((slot[j] & 3) * 8));
                         }
                     }
@@ -286,7 +288,7 @@ __global__ void __launch_bounds__(NT) k_score(const DevItem* __restrict__ items,
         uint32_t rmask = 0;   // slots to reset (touched at all)
 #pragma unroll
         for (int j = 0; j < SPT; j++)
-            if (__float_as_uint(v[j]) != kSentinelBits) rmask |= 1u << j;
+            if (__float_as_uint(v[j]) != kTileEmptyBits) rmask |= 1u << j;
         tmask = rmask;
         if (AND) {
 #pragma unroll
@@ -345,7 +347,7 @@ __global__ void __launch_bounds__(NT) k_score(const DevItem* __restrict__ items,
                 const float th = s_theta;
                 uint32_t sl = (uint32_t)sb * NT + tid;
                 float sv = acc[sl];
-                bool ok = __float_as_uint(sv) != kSentinelBits;
+                bool ok = __float_as_uint(sv) != kTileEmptyBits;
                 if (AND) ok = ok && (((mcnt[sl >> 2] >> (8 * (sl & 3))) & 0xFFu) == required);
                 if (ok && sv >= th) {
                     uint32_t pos = atomicAdd(&s_cnt, 1u);
@@ -355,8 +357,8 @@ __global__ void __launch_bounds__(NT) k_score(const DevItem* __restrict__ items,
         }
         // reset touched slots for the next tile
         {
-            float4 sent4 = make_float4(__uint_as_float(kSentinelBits), __uint_as_float(kSentinelBits),
-                                       __uint_as_float(kSentinelBits), __uint_as_float(kSentinelBits));
+            float4 sent4 = make_float4(__uint_as_float(kTileEmptyBits), __uint_as_float(kTileEmptyBits),
+                                       __uint_as_float(kTileEmptyBits), __uint_as_float(kTileEmptyBits));
             float4* acc4 = reinterpret_cast<float4*>(acc);
 #pragma unroll
             for (int g = 0; g < NG; g++) {

@@ -40,8 +40,8 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
     const gp_f32 pnorm = (gp_f32)seg.pnorm;
     const gp_u2 stream = IMP ? (gp_u2)seg.impacts : postings;   // IMP: {docId, precomputed term score bits} (see dscore_body)
 
-    const float4 sent4 = make_float4(__uint_as_float(kSentinelBits), __uint_as_float(kSentinelBits),
-                                     __uint_as_float(kSentinelBits), __uint_as_float(kSentinelBits));
+    const float4 sent4 = make_float4(__uint_as_float(kTileEmptyBits), __uint_as_float(kTileEmptyBits),
+                                     __uint_as_float(kTileEmptyBits), __uint_as_float(kTileEmptyBits));   // see ns_internal.h
     float4* v4 = reinterpret_cast<float4*>(vals);
 #pragma unroll
     for (int g = 0; g < NG; g++) v4[g * 64 + lane] = sent4;
@@ -189,8 +189,11 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
                         if (takem[j] == 0ull) continue;   /* uniform */                            \
                         if (__builtin_amdgcn_inverse_ballot_w64(takem[j])) old[j] = vals[slot[j]]; \
                         /* `found` (:495) counts a doc when its slot is touched for the first time (OR mode; the */ \
-                        /* conjunctive extension counts in the read-back, where the per-doc term counts are known) */ \
-                        if (!AND) found_s += (uint32_t)__popcll(takem[j] & wballot(__float_as_uint(old[j]) == kSentinelBits)); \
+                        /* conjunctive extension counts in the read-back, where the per-doc term counts are known); */ \
+                        /* a first touch starts from the reference's +0.0f (:480), whatever the contribution is */ \
+                        const bool fresh_ = __float_as_uint(old[j]) == kTileEmptyBits;             \
+                        if (!AND) found_s += (uint32_t)__popcll(takem[j] & wballot(fresh_));       \
+                        old[j] = fresh_ ? 0.0f : old[j];                                           \
                     }                                                                              \
                 }
                 if (n <= 64u) NS_TILE_PAIR(0, 1) else NS_TILE_PAIR(0, 2);
@@ -200,7 +203,7 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
                 for (int j = 0; j < E; j++) {
                     if (takem[j] == 0ull) continue;   // uniform
                     if (__builtin_amdgcn_inverse_ballot_w64(takem[j])) {
-                        vals[slot[j]] = old[j] + wq * x[j];   // -0.0f (untouched) + x == x exactly
+                        vals[slot[j]] = old[j] + wq * x[j];
                         if (AND) mcnt[slot[j]] = (uint8_t)(mcnt[slot[j]] + 1);
                     }
                 }
@@ -244,17 +247,17 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
             v4[g * 64 + lane] = sent4;
             uint32_t cw = 0;
             if (AND) { cw = reinterpret_cast<const uint32_t*>(mcnt)[g * 64 + lane]; reinterpret_cast<uint32_t*>(mcnt)[g * 64 + lane] = 0; }
-            // Once K candidates with non-negative scores exist (theta >= 0) an untouched slot (-0.0f) can
-            // never beat theta: one max + one compare per four slots decides whether anything is offered.
-            if (!AND && theta >= 0.0f && !ge_mode) {
+            // An untouched slot holds a NaN, which never compares above (or equal to) theta, and fmax ignores it:
+            // one max + one compare per four slots decides whether anything here can be offered.
+            if (!AND) {
                 const float mx = __builtin_fmaxf(__builtin_fmaxf(vv[0], vv[1]), __builtin_fmaxf(vv[2], vv[3]));
-                if (wballot(mx > theta) == 0ull) continue;
+                if ((ge_mode ? wballot(mx >= theta) : wballot(mx > theta)) == 0ull) continue;
             }
             uint64_t scm[4];
             uint64_t anyq = 0ull;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                scm[c] = wballot(__float_as_uint(vv[c]) != kSentinelBits);
+                scm[c] = wballot(__float_as_uint(vv[c]) != kTileEmptyBits);
                 if (AND) {
                     scm[c] &= wballot(((cw >> (8 * c)) & 0xFFu) == T);   // conjunctive extension
                     found_s += (uint32_t)__popcll(scm[c]);
@@ -360,7 +363,7 @@ __global__ void __launch_bounds__(64 * kUscoreWavesPerBlock) __attribute__((amdg
     DevWItem it = items[item_idx];
     const bool tiles = (it.whole & 2u) != 0;
     const bool thin = (it.whole & 4u) != 0;   // the non-driver lists are thin: smallest foreign budget
-    it.whole &= 9u;   // bit 0: whole segment, bit 3: short division
+    it.whole &= 25u;   // bit 0: whole segment, bit 3: short division, bit 4: signed inputs
     if (thin)
         dscore_body<HK / 2, 64, AND, CB, IMP>(it, terms, segs, s_tbl[wave], s_vals[wave], s_mcnt[wave], s_cand[wave],
                                  s_tab[wave], s_aux[wave], out_hits, out_nhits, out_found, K, lane);

@@ -29,7 +29,7 @@ _ensure_built()
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 # hit-list fixtures (found + per hit: segment, docId, score bits); meta1.json holds JSON TEXT of the reference instead
-GOLDEN_NAMES = sorted(f[:-5] for f in os.listdir(GOLDEN_DIR) if f.endswith(".json") and f not in ("meta1.json", "invert1.json", "sem1.json", "segwriter1.json", "cache1.json", "semload1.json"))
+GOLDEN_NAMES = sorted(f[:-5] for f in os.listdir(GOLDEN_DIR) if f.endswith(".json") and f not in ("meta1.json", "invert1.json", "sem1.json", "segwriter1.json", "cache1.json", "semload1.json", "fullsize.json"))
 
 
 def load_golden(name):

@@ -145,6 +145,33 @@ def run_ref_driver(index_dir, queries, k, workdir):
     return res
 
 
+def batch_digests(hits, nhits, found, block=1024):
+    """Digests of a whole batch's results (shared by tools/gen_golden.py and tests/test_gpu_parity.py).
+    exact[b]: SHA-256 over block b's found, nhits and the valid hits' (score bits, seg, doc) in rank order — the
+              canonical order (score desc, seg asc, doc asc), what the oracle and the HIP path return;
+    ties[b]:  SHA-256 over found, nhits and each query's score bits SORTED — invariant under the order inside
+              equal-score runs, which the reference leaves to its hash table: comparable with the REAL
+              reference's answers."""
+    import hashlib
+    Q, K = hits.shape
+    out = {"exact": [], "ties": []}
+    for b0 in range(0, Q, block):
+        he, ht = hashlib.sha256(), hashlib.sha256()
+        b1 = min(Q, b0 + block)
+        head = np.asarray(found[b0:b1], dtype="<u8").tobytes() + np.asarray(nhits[b0:b1], dtype="<u4").tobytes()
+        he.update(head)
+        ht.update(head)
+        for q in range(b0, b1):
+            n = int(nhits[q])
+            h = hits[q, :n]
+            bits = h["score"].view(np.uint32)
+            he.update(np.stack([bits, h["seg"], h["doc"]], axis=1).astype("<u4").tobytes())
+            ht.update(np.sort(bits).astype("<u4").tobytes())
+        out["exact"].append(he.hexdigest())
+        out["ties"].append(ht.hexdigest())
+    return out
+
+
 def tie_aware_equal(got_hits, got_found, oracle, query, k, flags=FLAG_OR):
     """SURVEY.md §8(c) tie policy.  `got_hits` is a list of (seg, doc, score_bits) in rank order from an
     implementation whose order inside equal-score runs is unspecified (the real reference).  It is

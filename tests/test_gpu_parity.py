@@ -71,7 +71,7 @@ def test_gpu_equals_oracle_and_reference_golden(name, engines):
             assert [int(b) for b in gh[qi, : gn[qi]]["score"].view(np.uint32)] == [h[2] for h in ref["hits"]]
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 12, 13, 14, 15, 16, 17, 18, 19, 20])
 def test_kernel_variants_agree(variant, engines):
     """Wave-private kernel (5/6/7: 256/512/1024-entry tables) and workgroup-tile kernel (1..4)."""
     g, eng, ora = engines("mid1")
@@ -87,7 +87,7 @@ def test_kernel_variants_agree(variant, engines):
 
 
 @pytest.mark.parametrize("variant,min_items,split", [(3, 1, 0), (3, 64, 0), (3, 4096, 0), (0, 1, 1 << 30), (0, 1, 500),
-                                                      (0, 4096, 0), (5, 1, 64), (7, 100000, 1000), (12, 1, 1 << 30), (12, 1, 300), (13, 4096, 0), (14, 100000, 1000), (19, 1, 1 << 30), (18, 1, 300), (20, 4096, 0)])
+                                                      (0, 4096, 0), (15, 1, 64), (17, 100000, 1000), (12, 1, 1 << 30), (12, 1, 300), (13, 4096, 0), (14, 100000, 1000), (19, 1, 1 << 30), (18, 1, 300), (20, 4096, 0)])
 def test_doc_range_splitting_is_invisible(variant, min_items, split, engines):
     """Queries are split into doc ranges (by posting budget, and to fill the chip for small batches)
     and re-joined on the device by k_merge; the result must not depend on the split."""
@@ -105,6 +105,143 @@ def test_doc_range_splitting_is_invisible(variant, min_items, split, engines):
             eng8.set_tuning(0, 0, 0)
     finally:
         eng.set_tuning(0, 0, 0)
+
+
+def test_retired_variants_are_rejected(engines):
+    g, eng, ora = engines("mid1")
+    for v in (5, 6, 7, 8, 9, 10, 11, 21, 1000):
+        with pytest.raises(RuntimeError, match="unknown kernel variant"):
+            eng.set_tuning(v, 0, 0)
+    eng.set_tuning(0, 0, 0)
+
+
+@pytest.mark.parametrize("variant,split", [(0, 0), (0, 300), (12, 0), (13, 200), (18, 0), (19, 0), (20, 300), (2, 0)])
+def test_zero_tf_postings_and_signed_weights(variant, split):
+    """`found` (src/api_engine.cpp:495) counts a doc once some term touches it, whatever the contribution: a posting
+    with tf == 0 contributes an exact zero, and with a negative idf or weight that zero is -0.0f, which the
+    reference's `0.0f + x` turns into +0.0f.  Raw C-ABI, one segment with tf == 0 postings sprinkled into dense and
+    sparse lists, positive and negative idfs / weights, every scoring body: found, order and score BITS against a
+    numpy fp32 restatement that starts every doc at +0.0f."""
+    L = nsbind.hip_lib()
+    ctx = C.c_void_p()
+    assert L.ns_ctx_create(0, C.byref(ctx)) == 0
+    try:
+        N = 6000
+        rng = np.random.default_rng(495)
+        doc_len = rng.integers(20, 3000, size=N, dtype=np.uint32)
+        avgdl = float(np.float32(doc_len.astype(np.float64).mean()))
+        sizes = [4200, 3900, 700, 60, 2500, 5]
+        lists, payload = [], []
+        for n in sizes:
+            docs = np.sort(rng.choice(N, size=n, replace=False)).astype(np.uint32)
+            tfs = rng.integers(1, 9, size=n, dtype=np.uint32)
+            tfs[rng.random(n) < 0.3] = 0                       # tf == 0: never written by the indexers, but legal bytes
+            lists.append((docs, tfs))
+            payload.append(np.stack([docs, tfs], axis=1).astype(np.uint32).ravel())
+        flat = np.concatenate(payload)
+        offs = np.cumsum([0] + [len(p) * 4 for p in payload])[:-1]
+        seg = C.c_void_p()
+        assert L.ns_segment_upload(ctx, 0, N, C.c_float(avgdl), doc_len.ctypes.data, flat.ctypes.data, flat.nbytes, C.byref(seg)) == 0, L.ns_last_error(ctx)
+        assert L.ns_set_tuning(ctx, variant, 0, split) == 0
+        idfs = [1.5, -2.25, 3.0, -0.75, 0.5, 4.0]
+        wts = [1.0, 1.0, -0.5, 0.6, -1.0, 1.0]
+        queries = [[0, 1], [1, 0], [1], [3], [1, 4], [4, 1, 3], [0, 1, 2, 3, 4, 5], [2, 5], [5, 3, 1], [1, 1], [0], [3, 2]]
+        qd = np.zeros(len(queries), dtype=nsbind.QDESC_DTYPE)
+        refs = []
+        for qi, q in enumerate(queries):
+            qd[qi] = (len(refs), len(q))
+            for li in q:
+                refs.append((0, len(lists[li][0]), int(offs[li]), idfs[li], wts[li]))
+        refs = np.array(refs, dtype=nsbind.TERM_DTYPE)
+        for k in (10, 100):
+            rc, hits, nhits, found = nsbind.search_batch_raw(ctx, qd, refs, k)
+            assert rc == 0, L.ns_last_error(ctx)
+            for qi, q in enumerate(queries):
+                acc = _np_bm25(lists, q, [idfs[li] for li in q], [wts[li] for li in q], doc_len, avgdl)
+                assert int(found[qi]) == len(acc), (variant, split, k, qi, int(found[qi]), len(acc))
+                keyed = sorted(acc.items(), key=lambda kv: (-float(kv[1]), kv[0]))[:k]
+                n = int(nhits[qi])
+                assert n == len(keyed)
+                want_bits = np.array([v for _, v in keyed], dtype=np.float32).view(np.uint32)
+                np.testing.assert_array_equal(hits[qi, :n]["score"].view(np.uint32), want_bits, err_msg=f"v{variant} q{qi} k{k}")
+                # docs: equal inside every run of equal scores (the numpy sort above breaks ties the canonical way: docId)
+                assert [int(d) for d in hits[qi, :n]["doc"]] == [d for d, _ in keyed], (variant, qi, k)
+                assert not np.any(hits[qi, :n]["score"].view(np.uint32) == 0x80000000), "the reference never returns -0.0f"
+        assert L.ns_segment_release(ctx, seg) == 0
+    finally:
+        L.ns_ctx_destroy(ctx)
+
+
+def test_full_batches_equal_oracle_and_reference_digests(index_factory):
+    """BASELINE configs 2-5 at FULL size, EVERY query of every batch: tests/golden/fullsize.json holds, per block of
+    1024 queries, SHA-256 digests of the whole batch's answers — `exact` from the oracle (found, nhits, every hit's
+    score bits / segment / docId in rank order), `ties` from the REAL reference run over the same full batches
+    (tie-order-invariant: found, nhits, sorted score bits).  Only the digests travel to the GPU box."""
+    from conftest import load_golden
+    g = load_golden("fullsize")
+    for cfg, e in g["configs"].items():
+        gen, Q, K, flags, (nseg, docs) = workloads.WORKLOADS[cfg]
+        assert (Q, K, flags, [nseg, docs]) == (e["queries"], e["k"], e["flags"], e["index"])
+        d, _ = index_factory(nseg, docs, 65536, 1337, False)
+        eng = nsbind.Engine(d, 0)
+        try:
+            hits, nhits, found, usable = eng.search_batch(gen(Q), K, flags)
+            assert usable.all()
+            dig = orc.batch_digests(hits, nhits, found, g["block"])
+            bad = [b for b, (x, y) in enumerate(zip(dig["exact"], e["exact"])) if x != y]
+            assert not bad, f"{cfg}: blocks {bad[:8]} of {len(e['exact'])} differ from the oracle's digests"
+            if "ties" in e:
+                bad = [b for b, (x, y) in enumerate(zip(dig["ties"], e["ties"])) if x != y]
+                assert not bad, f"{cfg}: blocks {bad[:8]} differ from the real reference's tie-invariant digests"
+            # the optional impact stream must not change a byte either
+            if cfg in ("cfg5", "cfg3"):
+                eng.build_impacts()
+                h2, n2, f2, _ = eng.search_batch(gen(Q), K, flags)
+                assert hits.tobytes() == h2.tobytes() and nhits.tobytes() == n2.tobytes() and found.tobytes() == f2.tobytes()
+        finally:
+            eng.close()
+
+
+def test_fixed_seed_fuzz_slice():
+    """A bounded, fixed-seed slice of tools/fuzz_parity.py (random index shapes, query laws, K, OR/AND, work-splitting
+    knobs, impact streams on/off) against the oracle, so that the driver's GPU run sees the differential test too."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_parity
+    cases, bad = fuzz_parity.run(seconds=45.0, seed=20261004, max_cases=160, verbose=False)
+    assert bad is None, bad
+    assert cases >= 40
+
+
+def test_reload_streams_inverted_files_without_a_host_copy(index_factory):
+    """north_star: "segment files are mmapped and pinned-copied once per segment".  Opening a second engine on the same
+    4 x 1M-doc index (222 MB of postings) must grow the process's resident set by about what a HOST-ONLY engine costs
+    (lexicons + docs), not by that plus the posting payload."""
+    import gc
+
+    def rss_mb():
+        with open("/proc/self/statm") as f:
+            return int(f.read().split()[1]) * os.sysconf("SC_PAGE_SIZE") / 2**20
+
+    d, total = index_factory(4, 1_000_000, 65536, 1337, False)
+    payload_mb = total * 8 / 2**20
+    warm = nsbind.Engine(d, 0)          # HIP runtime, code objects, pinned pools: paid once
+    gc.collect()
+    r0 = rss_mb()
+    host_only = nsbind.Engine(d, -1)
+    r1 = rss_mb()
+    dev = nsbind.Engine(d, 0)
+    r2 = rss_mb()
+    try:
+        host_cost, dev_cost = r1 - r0, r2 - r1
+        assert payload_mb > 200
+        assert dev_cost < host_cost + 0.35 * payload_mb, (host_cost, dev_cost, payload_mb)
+        # and the device copy is complete: same answers as the first engine
+        qs = workloads.cfg5_queries(64)
+        a, b = warm.search_batch(qs, 10), dev.search_batch(qs, 10)
+        assert all(x.tobytes() == y.tobytes() for x, y in zip(a, b))
+    finally:
+        warm.close(); host_only.close(); dev.close()
 
 
 def test_and_extension_matches_derived_oracle(engines):

@@ -129,12 +129,27 @@ def test_tokenizer_and_base_terms():
 
 
 def test_idf_matches_reference_expression():
+    """bm25_idf (src/api_engine.cpp:45-47) BIT FOR BIT: `N - df` is a u32 subtraction (it wraps when df > N), then
+    int -> float, two fp32 additions, an fp32 division, and glibc's logf — restated here with numpy fp32 scalars and
+    the C library's logf called through ctypes (the function the reference's std::log(float) resolves to)."""
+    import ctypes
+    import ctypes.util
+    libm = ctypes.CDLL(ctypes.util.find_library("m"))
+    libm.logf.argtypes = [ctypes.c_float]
+    libm.logf.restype = ctypes.c_float
     L = nsbind.host_lib()
-    for N, df in [(1000, 1), (1000, 999), (1000, 1000), (1_000_000, 600_000), (5, 9), (0, 0)]:
-        num = np.float32(np.uint32((N - df) & 0xFFFFFFFF)) + np.float32(0.5)   # u32 subtraction first (wraps when df > N)
-        want = np.log(np.float32(num / (np.float32(df) + np.float32(0.5))) + np.float32(1.0), dtype=np.float32)
-        got = np.float32(L.nsh_bm25_idf(N, df))
-        assert abs(float(got) - float(want)) <= 1e-6 * max(1.0, abs(float(want)))
+    f = np.float32
+    rng = np.random.default_rng(45)
+    cases = [(1000, 1), (1000, 999), (1000, 1000), (1_000_000, 600_000), (5, 9), (0, 0), (1, 0), (2**32 - 1, 1), (16_777_217, 3),
+             (125_000, 74_907), (1_000_000, 599_412)]
+    cases += [(int(n), int(d)) for n, d in zip(rng.integers(1, 2**31, 4000), rng.integers(0, 2**31, 4000))]
+    cases += [(int(n), int(rng.integers(0, n + 1))) for n in rng.integers(1, 5_000_000, 4000)]
+    for N, df in cases:
+        num = f(np.uint32((N - df) & 0xFFFFFFFF)) + f(0.5)
+        den = f(np.uint32(df)) + f(0.5)
+        want = f(libm.logf(ctypes.c_float(float(f(f(num / den) + f(1.0))))))
+        got = f(L.nsh_bm25_idf(N, df))
+        assert got.view(np.uint32) == want.view(np.uint32), (N, df, float(got), float(want))
 
 
 def test_build_refs_layout(golden_index):

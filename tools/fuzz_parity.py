@@ -38,17 +38,22 @@ def same(gpu, ora):
     return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--seconds", type=float, default=240.0)
-    ap.add_argument("--seed", type=int, default=1)
-    args = ap.parse_args()
-    rng = random.Random(args.seed)
+def run(seconds, seed, max_cases=None, verbose=True):
+    """Returns (batches checked, None) or (batches checked, description of the first mismatch)."""
+    import shutil
+    rng = random.Random(seed)
     t0 = time.time()
     last = t0
     cases = 0
     tmp = tempfile.mkdtemp(prefix="ns_fuzz_")
-    while time.time() - t0 < args.seconds:
+    try:
+        return _run(rng, t0, last, cases, tmp, seconds, max_cases, verbose)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def _run(rng, t0, last, cases, tmp, seconds, max_cases, verbose):
+    while time.time() - t0 < seconds and (max_cases is None or cases < max_cases):
         nseg = rng.choice([1, 1, 2, 3, 5])
         docs = rng.choice([300, 2000, 9000, 40000, 120000])
         vocab = rng.choice([64, 512, 4096, 16384])
@@ -83,16 +88,30 @@ def main():
                 eng.use_impacts(imp)
                 bad = same(eng.search_batch(qs, k, flags), ora.search_batch(qs, k, flags, threads=8))
                 if bad:
-                    print(f"MISMATCH {bad}: index(nseg={nseg}, docs={docs}, vocab={vocab}, seed={seed}) law={law} nq={nq} k={k} flags={flags} tune={tune} impacts={imp}")
-                    print("queries:", qs[:5])
-                    sys.exit(1)
+                    return cases, (f"MISMATCH {bad}: index(nseg={nseg}, docs={docs}, vocab={vocab}, seed={seed}) law={law} nq={nq} k={k} "
+                                   f"flags={flags} tune={tune} impacts={imp} queries={qs[:5]}")
                 cases += 1
-                if time.time() - last > 30:
+                if verbose and time.time() - last > 30:
                     last = time.time()
                     print(f"... {cases} batches so far ({last - t0:.0f} s)", flush=True)
         finally:
             eng.close()
             ora.close()
+            import shutil
+            shutil.rmtree(idx, ignore_errors=True)
+    return cases, None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=240.0)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    t0 = time.time()
+    cases, bad = run(args.seconds, args.seed)
+    if bad:
+        print(bad)
+        sys.exit(1)
     print(f"fuzz: {cases} batches equal to the oracle in {time.time() - t0:.0f} s (seed {args.seed})")
 
 

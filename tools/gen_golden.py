@@ -15,6 +15,7 @@ import random
 import shutil
 import sys
 import tempfile
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "nextsearch-api_amd"))
@@ -271,6 +272,74 @@ def make_semload_fixture(outdir):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def make_fullsize_fixture(outdir, procs=8):
+    """BASELINE configs 2-5 at FULL size (1 M docs; 16384 / 4096 / 4096 / 1024 queries): digests of the whole batches'
+    answers.  `exact`: the oracle (oracle/bm25_oracle.c, itself pinned by the goldens above).  `ties`: the REAL reference
+    (oracle/_ref/ref_driver, `procs` processes on contiguous slices of the batch), for the OR configs — and the
+    generator asserts that the oracle's own tie-invariant digests equal the reference's before it writes anything."""
+    import subprocess
+    import numpy as np
+    fixture = {"name": "fullsize", "block": 1024, "configs": {},
+               "source": "exact: oracle/bm25_oracle.c over the full batches; ties: cord19::Engine::search of /root/reference over the full batches (oracle/_ref/ref_driver)"}
+    tmp = tempfile.mkdtemp(prefix="ns_golden_full_")
+    try:
+        made = {}
+        for cfg in ("cfg2", "cfg3", "cfg4", "cfg5"):
+            gen, Q, K, flags, (nseg, docs) = workloads.WORKLOADS[cfg]
+            if (nseg, docs) not in made:
+                idx = os.path.join(tmp, f"i_{nseg}_{docs}")
+                nsbind.gen_index(idx, nseg, docs, 65536, 1337, False)
+                made[(nseg, docs)] = idx
+            idx = made[(nseg, docs)]
+            queries = gen(Q)
+            ora = orc.Oracle(idx)
+            t0 = time.time()
+            hits, nhits, found, usable = ora.search_batch(queries, K, flags, threads=procs)
+            ora.close()
+            assert usable.all()
+            dig = orc.batch_digests(hits, nhits, found)
+            entry = {"queries": Q, "k": K, "flags": flags, "index": [nseg, docs], "exact": dig["exact"], "oracle_seconds": round(time.time() - t0, 1)}
+            if flags == 0:   # the reference has no conjunctive mode (SURVEY 8(c))
+                t0 = time.time()
+                per = (Q + procs - 1) // procs
+                jobs = []
+                for i in range(procs):
+                    sub = queries[i * per:(i + 1) * per]
+                    if not sub:
+                        continue
+                    wd = os.path.join(tmp, f"w_{cfg}_{i}")
+                    os.makedirs(wd)
+                    qp, op = os.path.join(wd, "q.txt"), os.path.join(wd, "o.txt")
+                    open(qp, "w").write("\n".join(sub) + "\n")
+                    jobs.append((subprocess.Popen([orc.REF_DRIVER, "search", idx, qp, str(K), op], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL), op, len(sub)))
+                r_hits = np.zeros((Q, K), dtype=orc.HIT_DTYPE)
+                r_nhits = np.zeros(Q, dtype=np.uint32)
+                r_found = np.zeros(Q, dtype=np.uint64)
+                q = 0
+                for pr, op, n in jobs:
+                    assert pr.wait() == 0
+                    res = orc.parse_driver_output(op)
+                    assert len(res) == n
+                    for r in res:
+                        r_found[q] = r["found"]
+                        r_nhits[q] = len(r["hits"])
+                        for j, (sg, dc, bits) in enumerate(r["hits"]):
+                            r_hits[q, j] = (np.array([bits], dtype=np.uint32).view(np.float32)[0], sg, dc)
+                        q += 1
+                assert q == Q
+                rdig = orc.batch_digests(r_hits, r_nhits, r_found)
+                assert rdig["ties"] == dig["ties"], f"{cfg}: the oracle's answers differ from the real reference's over the full batch"
+                entry["ties"] = rdig["ties"]
+                entry["reference_seconds"] = round(time.time() - t0, 1)
+            fixture["configs"][cfg] = entry
+            print(cfg, {k: v for k, v in entry.items() if k not in ("exact", "ties")}, flush=True)
+        with open(os.path.join(outdir, "fullsize.json"), "w") as f:
+            json.dump(fixture, f, separators=(",", ":"))
+        print("fullsize bytes", os.path.getsize(os.path.join(outdir, "fullsize.json")))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def segwriter_spec(n_docs=150, seed=31):
     """Logical documents for the reference's SegmentWriter: cord_uid, title, json_relpath, doc_len, term:tf ..."""
     rng = random.Random(seed)
@@ -354,6 +423,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "segwriter":
         make_segwriter_fixture(os.path.join(ROOT, "tests", "golden"))
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "fullsize":
+        make_fullsize_fixture(os.path.join(ROOT, "tests", "golden"))
         return
     if len(sys.argv) > 1 and sys.argv[1] == "semload":
         make_semload_fixture(os.path.join(ROOT, "tests", "golden"))
