@@ -1358,3 +1358,15 @@ extern "C" int ns_sem_topk(ns_ctx* ctx, ns_sem* sem, const float* qvecs, uint32_
     if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? NS_E_NOMEM : NS_E_HIP, "ns_sem_topk: %s", hipGetErrorString(e));
     return NS_OK;
 }
+
+#ifdef NS_COUNT
+// Diagnostic build only: the driver-stream body's event counters (ns_driver_kernel.hip), optionally reset.
+extern "C" int ns_debug_counters(unsigned long long* out, int reset) {
+    unsigned long long h[16];
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(ns::g_ns_cnt), sizeof(h)) != hipSuccess) return -1;
+    if (out) std::memcpy(out, h, sizeof(h));
+    if (reset) { std::memset(h, 0, sizeof(h)); if (hipMemcpyToSymbol(HIP_SYMBOL(ns::g_ns_cnt), h, sizeof(h)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif

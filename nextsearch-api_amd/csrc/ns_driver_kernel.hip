@@ -29,6 +29,15 @@
 
 namespace ns {
 
+#ifdef NS_COUNT
+// Diagnostic build only (make -C nextsearch-api_amd count): event counts of the driver-stream body, summed over all
+// items of all launches since the last reset; read through ns_debug_counters (tools/dbg/count_run.py).
+__device__ unsigned long long g_ns_cnt[16];
+#define NS_CNT(i, v) cnt_[(i)] += (unsigned long long)(v)
+#else
+#define NS_CNT(i, v)
+#endif
+
 // NB  buckets of 4 entries per wave   FB  foreign postings per super-batch (<= 256: the owner index has 8 bits).
 // A driver lookup reads ONE bucket and stops unless the bucket is full and holds no match: with FB/NB <= 0.75
 // a full bucket is a < 1% event, so practically every lookup is a single ds_read_b128 for all 64 lanes.
@@ -113,6 +122,11 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
     }
     if ((uint32_t)lane == dl) { cur = end; }   // the driver is streamed through d_cur, not through its lane
 
+#ifdef NS_COUNT
+    unsigned long long cnt_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    NS_CNT(0, 1);
+    NS_CNT(10, T);
+#endif
     uint32_t lo = it.doc_lo;
     const uint32_t last_doc = it.doc_hi - 1;   // host guarantees doc_hi > doc_lo and doc_hi <= n_docs
     float theta = -__builtin_inff();
@@ -182,6 +196,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
     wave_sync();
     for (;;) {
         ge_mode = false;
+        NS_CNT(1, 1);
         // ================= 1. foreign windows of this super-batch (planned one super-batch ahead) ==========
         const uint32_t w = w_n;
         const uint32_t e = e_n;
@@ -274,6 +289,11 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
                 if ((uint32_t)lane != dl) { cur += w; if (cur > end) cur = end; }
                 batch_consumed = total;
             }
+            NS_CNT(2, 1);                       // super-batches with foreign postings
+            NS_CNT(3, total);                   // foreign postings loaded (window sizes)
+            NS_CNT(4, batch_consumed);          // ... of which consumed
+            NS_CNT(5, (total + 63) / 64);       // foreign chunks
+            NS_CNT(11, (uint32_t)__popcll(wballot(w > 0)));   // active foreign terms
             Rf = (Rf > batch_consumed) ? (Rf - batch_consumed) : 0;
             NS_PLAN_FOREIGN();   // cursors are final: the next super-batch's probes fly from here on
             // ---- BM25 term scores (src/api_engine.cpp:477-480, operation for operation) ----
@@ -323,6 +343,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
                 uint32_t pos = 0;
                 for (int round = 0; round < 8 * NB; round++) {
                     if (wballot(pending) == 0ull) break;
+                    NS_CNT(6, 1);               // claim iterations
                     if (wballot(scan) != 0ull) {
                         if (scan) {
                             const uint4 q = ent4[b];
@@ -362,6 +383,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
 #define NS_FOREIGN_RMW(ta, tb)                                                                     \
         for (uint32_t tt = (ta); tt <= (tb); tt++) {                                               \
             if (tt == dl) continue;                                                                \
+            NS_CNT(7, 1);                                                                          \
             float old_[FE];                                                                        \
             _Pragma("unroll") for (int j = 0; j < FE; j++) {                                       \
                 old_[j] = 0.0f;                                                                    \
@@ -398,6 +420,8 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
                 nr[j] = IMP ? 0.0f : np[j * 64 + lane];
             }
             uint32_t cnt = 0, r_hits = 0;
+            NS_CNT(8, 1);                       // driver rounds (256 postings loaded each)
+            NS_CNT(12, (n + 63) / 64);          // driver chunks with postings
             float dx[DE];
             uint64_t dokm[DE];   // postings of this round that belong to the super-batch and are still private
             if (n == (uint32_t)(DE * 64)) {   // a full round (all but a list's last): no lane mask to build
@@ -502,6 +526,9 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
                     NS_OFFER_M(dokm[j], dx[j], ps[j].x);
                 }
             }
+            NS_CNT(9, cnt);                     // driver postings consumed
+            NS_CNT(13, any_foreign_here ? (n + 63) / 64 : 0);   // chunks that probed the table
+            NS_CNT(14, r_hits);
             d_cur += cnt;
             driver_progress = driver_progress || (cnt > 0);
             if (cnt < n) break;   // reached hi
@@ -578,6 +605,10 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
         out_nhits[it.out_slot] = n;
         out_found[it.out_slot] = (uint64_t)found + (uint64_t)found_s;
     }
+#ifdef NS_COUNT
+    if (lane == 0)
+        for (int i = 0; i < 16; i++) if (cnt_[i]) atomicAdd(&g_ns_cnt[i], cnt_[i]);
+#endif
 }
 
 // HK = table entries per wave (4 per bucket)

@@ -1,28 +1,35 @@
 #!/usr/bin/env python3
-"""Diagnostic: event counts of the driver-stream body (needs the -DNS_STAMP build copied over
-nextsearch-api_amd/libnextsearch_hip.so on the GPU box)."""
+"""Diagnostic: event counts of the driver-stream body per query law (GPU box only).  Needs the counting build:
+    make -C nextsearch-api_amd count        (here; the .so travels with the snapshot)
+    on the GPU box (a scratch copy of the tree): cp nextsearch-api_amd/libnextsearch_hip_count.so nextsearch-api_amd/libnextsearch_hip.so
+    python3 tools/dbg/count_run.py cfg5_gen,cfg5_thin,cfg5
+"""
 import ctypes as C, os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "nextsearch-api_amd")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import nsbind, law_bench
 L = nsbind.hip_lib()
-L.ns_debug_stamps.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+L.ns_debug_counters.argtypes = [C.POINTER(C.c_uint64), C.c_int]
 tmp = tempfile.TemporaryDirectory(); idx = os.path.join(tmp.name, "i")
 nsbind.gen_index(idx, 1, 1_000_000, 65536, 1337, False)
 eng = nsbind.Engine(idx, 0)
 laws = law_bench.laws()
-names = ["items", "super-batches", "sb with foreign", "foreign chunks", "claim iterations", "rmw term iters", "driver rounds",
-         "lookup chunks", "lookup slow entries", "hit branches", "-", "-", "foreign postings", "driver postings", "foreign window postings", "-"]
-for n in sys.argv[1].split(","):
+names = ["items (driver-stream body)", "super-batches", "super-batches with foreign postings", "foreign postings LOADED (windows)", "foreign postings consumed",
+         "foreign chunks", "claim iterations", "rmw term passes", "driver rounds (256 loaded each)", "driver postings consumed", "terms (sum over items)",
+         "active foreign terms (sum over sb)", "driver chunks with postings", "driver chunks that probed the table", "driver postings that hit the table", "-"]
+for n in (sys.argv[1] if len(sys.argv) > 1 else "cfg5_gen").split(","):
     qs, k = laws[n]
     b = eng.prepare(qs, k)
-    out = (C.c_uint64 * 32)()
-    L.ns_debug_stamps(out, 1)
+    out = (C.c_uint64 * 16)()
+    L.ns_debug_counters(out, 1)
     b.run(True); b.sync()
-    L.ns_debug_stamps(out, 1)
+    L.ns_debug_counters(out, 1)
     inf = b.info()
-    print(f"{n}: postings {inf.postings}, dscore items {out[31]}")
-    for i in range(16):
-        if names[i] != "-":
-            print(f"    {names[i]:>24}: {out[i]:>12}  ({out[i] / max(out[1], 1):8.2f} per super-batch)")
+    sb = max(out[1], 1)
+    print(f"{n}: postings {inf.postings}, kernel {inf.last_score_kernel_ms:.3f} ms")
+    for i in range(15):
+        print(f"    {names[i]:>40}: {out[i]:>12}  ({out[i] / sb:8.2f} per super-batch)")
+    print(f"    foreign window utilisation {out[4] / max(out[3], 1):.3f}; lanes used in foreign chunks {out[4] / max(out[5] * 64, 1):.3f}; "
+          f"driver round utilisation {out[9] / max(out[8] * 256, 1):.3f}; lanes used in driver chunks {out[9] / max(out[12] * 64, 1):.3f}; "
+          f"foreign share of consumed postings {out[4] / max(out[4] + out[9], 1):.3f}")
     b.close()
