@@ -129,6 +129,10 @@ int ns_segment_upload_end(ns_ctx* ctx, ns_seg* seg);
  * not overlap.  May be called again to add lists or to replace a list's idf. */
 int ns_segment_build_impacts(ns_ctx* ctx, ns_seg* seg, const uint64_t* byte_off, const uint32_t* counts,
                              const float* idfs, uint32_t n_lists);
+/* Host threads ns_batch_prepare may use for a large batch (regrouping the term refs, cutting work items, writing the
+ * descriptors): 0 = automatic (up to 8, one per ~1500 queries), 1 = the calling thread only.  The prepared batch — every
+ * descriptor byte and the launch order — does not depend on this number. */
+int ns_ctx_set_host_threads(ns_ctx* ctx, uint32_t n);
 /* on = 0: batches prepared from now on ignore impact streams (default: on = 1). */
 int ns_ctx_use_impacts(ns_ctx* ctx, int on);
 
@@ -147,9 +151,19 @@ int  ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const ns_term_r
  * all-gathered by RCCL): d_hits Q*K ns_hit, d_nhits Q u32, d_found Q u64.  NULLs restore the
  * batch's own buffers. */
 int  ns_batch_bind_outputs(ns_batch* b, void* d_hits, void* d_nhits, void* d_found);
-/* Enqueue one pass of the hot path on the ctx stream (asynchronous).  timed != 0 brackets the
- * kernels with HIP events on that stream (read back through ns_batch_get_info after a sync). */
-int  ns_batch_run(ns_batch* b, int timed);
+/* Enqueue one pass of the hot path on the ctx stream (asynchronous).  run_flags:
+ *   NS_RUN_TIMED  brackets the kernels with HIP events on that stream (read back through ns_batch_get_info after a
+ *                 sync or fetch);
+ *   NS_RUN_FETCH  also enqueues, right behind the kernels, the copy of the results into pinned host memory and
+ *                 records a completion event, so that a later ns_batch_fetch / ns_batch_destroy waits for THIS batch
+ *                 only.  That is what lets batches overlap on one ctx:
+ *                     prepare(i+1)   host threads regroup and upload while the device scores batch i
+ *                     run(i+1, NS_RUN_FETCH)
+ *                     fetch(i)       returns as soon as batch i's results have landed
+ *                 At most 8 batches may sit between their run and their fetch.  Not for batches with bound outputs. */
+#define NS_RUN_TIMED 1
+#define NS_RUN_FETCH 2
+int  ns_batch_run(ns_batch* b, int run_flags);
 int  ns_batch_sync(ns_batch* b);
 int  ns_batch_fetch(ns_batch* b, ns_hit* hits_out, uint32_t* nhits_out, uint64_t* found_out);
 int  ns_batch_get_info(ns_batch* b, ns_batch_info* info);

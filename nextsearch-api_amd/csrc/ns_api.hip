@@ -9,8 +9,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/nextsearch_hip.h"
@@ -25,6 +29,61 @@
 using namespace ns;
 
 static_assert(sizeof(ns_hit) == sizeof(Hit), "ns_hit layout");
+
+
+// Fork-join over a fixed set of host threads (ns_batch_prepare's phases).  run(n, fn) calls fn(0..n-1), task i on
+// worker i (the calling thread takes task 0), and returns when all are done.  Workers sleep between batches.
+class ForkJoin {
+public:
+    explicit ForkJoin(unsigned width) : width_(std::max(1u, width)) {
+        for (unsigned i = 1; i < width_; i++) workers_.emplace_back([this, i]() { loop(i); });
+    }
+    ~ForkJoin() {
+        { std::lock_guard<std::mutex> l(m_); stop_ = true; gen_++; }
+        wake_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    unsigned width() const { return width_; }
+    void run(unsigned n, const std::function<void(unsigned)>& fn) {
+        n = std::min(n, width_);
+        if (n <= 1) { if (n) fn(0); return; }
+        { std::lock_guard<std::mutex> l(m_); fn_ = &fn; n_ = n; pending_ = n - 1; gen_++; }
+        wake_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> l(m_);
+        done_.wait(l, [this]() { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+private:
+    void loop(unsigned me) {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(unsigned)>* fn = nullptr;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                wake_.wait(l, [&]() { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                if (me < n_) fn = fn_;
+            }
+            if (fn) {
+                (*fn)(me);
+                std::lock_guard<std::mutex> l(m_);
+                if (--pending_ == 0) done_.notify_one();
+            }
+        }
+    }
+    unsigned width_;
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable wake_, done_;
+    const std::function<void(unsigned)>* fn_ = nullptr;
+    unsigned n_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+struct ns_prep;
+static void prep_free(ns_prep* p);
 
 // ------------------------------------------------------------------------------------------------
 struct ns_seg {
@@ -89,7 +148,12 @@ struct ns_ctx {
     // A small batch has its result arrays IN h_down (pinned host memory is device-addressable): the kernels
     // write the few hits over PCIe themselves and fetch is a stream sync + memcpy.  One batch at a time owns it.
     struct ns_batch* down_owner = nullptr;
+    // pinned result buffers for batches in flight (NS_RUN_FETCH): one per batch between its run and its fetch
+    struct DownSlot { void* p = nullptr; size_t cap = 0; bool busy = false; };
+    std::vector<DownSlot> down_slots;
     bool use_impacts = true;   // batches take the impact stream when every list they touch has one (ns_ctx_use_impacts)
+    ns_prep* prep = nullptr;   // ns_batch_prepare's host threads and per-thread scratch, kept from batch to batch
+    unsigned prep_threads = 0; // 0 = automatic (up to 8); 1 = prepare on the calling thread only (ns_ctx_set_host_threads)
 };
 
 static thread_local std::string g_create_err;
@@ -217,8 +281,10 @@ extern "C" void ns_ctx_destroy(ns_ctx* ctx) {
     for (auto& blk : ctx->pool) (void)hipFree(blk.p);
     if (ctx->h_up) (void)hipHostFree(ctx->h_up);
     if (ctx->h_down) (void)hipHostFree(ctx->h_down);
+    for (auto& ds : ctx->down_slots) if (ds.p) (void)hipHostFree(ds.p);
     if (ctx->up_done) (void)hipEventDestroy(ctx->up_done);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    prep_free(ctx->prep);
     delete ctx;
 }
 
@@ -482,6 +548,13 @@ extern "C" int ns_segment_build_impacts(ns_ctx* ctx, ns_seg* seg, const uint64_t
     return NS_OK;
 }
 
+extern "C" int ns_ctx_set_host_threads(ns_ctx* ctx, uint32_t n) {
+    if (!ctx) return NS_E_INVAL;
+    if (n > 64) return fail(ctx, NS_E_INVAL, "ns_ctx_set_host_threads: %u threads (at most 64)", n);
+    ctx->prep_threads = n;
+    return NS_OK;
+}
+
 extern "C" int ns_ctx_use_impacts(ns_ctx* ctx, int on) {
     if (!ctx) return NS_E_INVAL;
     ctx->use_impacts = on != 0;
@@ -531,6 +604,11 @@ struct ns_batch {
     uint32_t n_wide_q = 0;
     size_t out_span = 0, off_nhits = 0, off_found = 0;   // [d_hits .. d_found end) is one contiguous span of the block
     std::vector<std::pair<void*, size_t>> blocks;   // every device block of this batch (returned to the ctx pool on destroy)
+    // pipelined use (NS_RUN_FETCH): the results' D2H copy into a pinned slot of the ctx is enqueued right behind the
+    // kernels and `done` is recorded after it, so that fetch / destroy wait for THIS batch only, not for the stream
+    hipEvent_t done = nullptr;
+    bool done_recorded = false;
+    int down_slot = -1;        // index into ns_ctx::down_slots while a D2H copy is pending or unread
 };
 
 static constexpr size_t kPoolMaxBytes = 1ull << 30;   // cached blocks beyond this are released
@@ -582,10 +660,15 @@ __global__ void __launch_bounds__(256) k_pull(uint4* __restrict__ dst, const uin
 extern "C" void ns_batch_destroy(ns_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
-    (void)hipStreamSynchronize(b->ctx->stream);
+    // nothing of THIS batch may still be in flight when its blocks go back to the pool; later batches on the same
+    // stream are none of its business (a pipelined caller destroys batch i while batch i+1 runs)
+    if (b->done_recorded) (void)hipEventSynchronize(b->done);
+    else (void)hipStreamSynchronize(b->ctx->stream);
     if (b->ctx->down_owner == b) b->ctx->down_owner = nullptr;
-    for (auto& blk : b->blocks) pool_free(b->ctx, blk.first, blk.second);   // the stream is idle: safe to hand on
+    if (b->down_slot >= 0) b->ctx->down_slots[(size_t)b->down_slot].busy = false;
+    for (auto& blk : b->blocks) pool_free(b->ctx, blk.first, blk.second);
     for (auto& e : b->ev_pool) if (e) (void)hipEventDestroy(e);
+    if (b->done) (void)hipEventDestroy(b->done);
     delete b;
 }
 
@@ -594,6 +677,78 @@ static hipError_t batch_alloc(ns_batch* b, void** dptr, size_t n) {
     if (e == hipSuccess) b->blocks.push_back({*dptr, n});
     return e;
 }
+// ---- host side of a batch: term refs -> (query, segment) groups -> work items, on several host threads ----------
+// A batch is prepared in three fork-join phases over contiguous slices of the queries (the reference's requests are
+// independent, src/api_engine.cpp:369): A regroup + classify, B cut into work items, C write the descriptors into the
+// pinned staging buffer in launch order.  Between the phases only prefix sums over the slices run serially.  Every
+// result (descriptor bytes, launch order) is independent of the number of threads.
+namespace {
+
+struct HostGroup { DevGroup g; uint32_t query; uint64_t cost; uint64_t cmax; uint64_t work; bool wave; uint8_t cls; bool fast_div; bool signed_in; };
+
+constexpr uint32_t kOrderBuckets = 2048;   // launch-order key: 6 bits of exponent x 5 bits of mantissa of the estimated run time
+inline uint32_t order_bucket(uint64_t c) {  // descending: bucket 0 holds the longest items
+    if (c < 32) return kOrderBuckets - 1 - (uint32_t)c;
+    const int b = 63 - __builtin_clzll(c);
+    const uint32_t key = (uint32_t)b * 32u + (uint32_t)((c >> (b - 5)) & 31u);
+    return kOrderBuckets - 1 - std::min(key, kOrderBuckets - 1);
+}
+
+struct PrepSlice {
+    uint32_t q0 = 0, q1 = 0;
+    std::vector<DevTerm> dterms;
+    std::vector<HostGroup> groups;
+    std::vector<uint32_t> qgroup_begin;   // q1 - q0 + 1 entries, local group indices
+    std::vector<uint32_t> seg_ids;
+    uint64_t bounds_total = 0, postings_total = 0, total_work = 0;
+    bool all_imp = true;
+    int err_code = NS_OK;
+    uint32_t err_query = 0xFFFFFFFFu;
+    std::string err_msg;
+    // phase B
+    std::vector<DevWItem> witems;
+    std::vector<uint16_t> wbucket;        // launch-order bucket of each wave item; bit 15: > 16 terms (the "wide" instantiation)
+    std::vector<DevItem> items;
+    std::vector<uint64_t> item_cost;
+    std::vector<DevGroup> bgroups;
+    uint32_t n_rows = 0;
+    bool direct = true;
+    std::vector<uint32_t> hist;           // [2][kOrderBuckets]: narrow, wide
+    // offsets handed down by the serial steps
+    uint32_t term_off = 0, row_off = 0, item_off = 0, bgroup_off = 0;
+    uint64_t bounds_off = 0;
+    std::vector<uint32_t> start;          // [2][kOrderBuckets]: this slice's first position in each bucket of the sorted item array
+    void reset(uint32_t a, uint32_t b) {
+        q0 = a; q1 = b;
+        dterms.clear(); groups.clear(); qgroup_begin.clear(); seg_ids.clear();
+        bounds_total = postings_total = total_work = 0; all_imp = true;
+        err_code = NS_OK; err_query = 0xFFFFFFFFu; err_msg.clear();
+        witems.clear(); wbucket.clear(); items.clear(); item_cost.clear(); bgroups.clear();
+        n_rows = 0; direct = true;
+        hist.assign(2 * kOrderBuckets, 0u);
+        start.assign(2 * kOrderBuckets, 0u);
+        term_off = row_off = item_off = bgroup_off = 0; bounds_off = 0;
+    }
+    void fail_at(uint32_t q, int code, const char* fmt, ...) {
+        if (err_code != NS_OK) return;   // the first failing query of the slice is reported
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        std::vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        err_code = code; err_query = q; err_msg = buf;
+    }
+};
+
+}  // namespace
+
+struct ns_prep {
+    std::vector<PrepSlice> slices;
+    ForkJoin* pool = nullptr;
+    ~ns_prep() { delete pool; }
+};
+static void prep_free(ns_prep* p) { delete p; }
+
 extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const ns_term_ref* terms, uint32_t n_queries,
                                 uint32_t k, uint32_t flags, ns_batch** out) {
     if (!ctx) return fail(nullptr, NS_E_INVAL, "ns_batch_prepare: ctx is NULL");
@@ -607,6 +762,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
     const VariantDesc vd = kVariants[ctx->variant];
     const uint32_t tile_docs = vd.nt * vd.spt;
     const bool wave_path = vd.hb != 0;
+    const bool auto_mode = ctx->variant == 0;
 
     // per-batch segment table (n_tiles depends on the workgroup-kernel variant)
     std::vector<DevSeg> segs(ctx->segs.size());
@@ -624,80 +780,114 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
         segs[i] = d;
     }
 
-    // ---- regroup term refs by (query, segment), keeping query-term order inside each group ----
-    struct HostGroup { DevGroup g; uint32_t query; uint64_t cost; uint64_t cmax; uint64_t work; bool wave; uint8_t cls; bool fast_div; bool signed_in; };
-    std::vector<DevTerm> dterms;
-    std::vector<HostGroup> groups;
-    std::vector<uint32_t> qgroup_begin(n_queries + 1, 0);
-    uint64_t bounds_total = 0, postings_total = 0;
-    bool all_imp = ctx->use_impacts && ctx->variant == 0;   // stays true while every list met so far has an impact stream built with this idf
-    std::vector<uint32_t> seg_ids;   // scratch
-    for (uint32_t q = 0; q < n_queries; q++) {
-        qgroup_begin[q] = (uint32_t)groups.size();
-        const ns_query_desc qd = queries[q];
-        if (qd.term_count && !terms) return fail(ctx, NS_E_INVAL, "terms is NULL");
-        seg_ids.clear();
-        for (uint32_t i = 0; i < qd.term_count; i++) {
-            const ns_term_ref& r = terms[qd.term_begin + i];
-            if (r.seg_id >= ctx->segs.size() || !ctx->segs[r.seg_id]) return fail(ctx, NS_E_INVAL, "query %u term %u: unknown segment %u", q, i, r.seg_id);
-            const ns_seg* s = ctx->segs[r.seg_id];
-            if (r.byte_off % 8 != 0) return fail(ctx, NS_E_INVAL, "query %u term %u: byte_off %llu not a multiple of 8", q, i, (unsigned long long)r.byte_off);
-            if (r.byte_off / 8 + r.count > s->n_postings) return fail(ctx, NS_E_INVAL, "query %u term %u: list [%llu,+%u) outside segment %u (%llu postings)", q, i, (unsigned long long)(r.byte_off / 8), r.count, r.seg_id, (unsigned long long)s->n_postings);
-            if (std::find(seg_ids.begin(), seg_ids.end(), r.seg_id) == seg_ids.end()) seg_ids.push_back(r.seg_id);
-        }
-        std::sort(seg_ids.begin(), seg_ids.end());   // segments in manifest (id) order, api_engine.cpp:441
-        for (uint32_t sid : seg_ids) {
-            HostGroup hg{};
-            hg.fast_div = ctx->segs[sid]->norm_safe;
-            hg.g.term_begin = (uint32_t)dterms.size();
-            hg.g.seg = sid;
-            hg.query = q;
-            for (uint32_t i = 0; i < qd.term_count; i++) {
-                const ns_term_ref& r = terms[qd.term_begin + i];
-                if (r.seg_id != sid) continue;
-                DevTerm t{};
-                t.list_off = r.byte_off / 8;
-                t.count = r.count;
-                t.idf = r.idf;
-                t.weight = r.qweight;
-                t.seg = sid;
-                dterms.push_back(t);
-                hg.cost += r.count;
-                hg.cmax = std::max<uint64_t>(hg.cmax, r.count);
-                if (all_imp) {
-                    uint32_t ib; std::memcpy(&ib, &r.idf, 4);
-                    all_imp = ctx->segs[sid]->imp_has((uint32_t)(r.byte_off / 8), r.count, ib);
-                }
-                // 2^-30 <= idf <= 2^30 (and finite): see ns_div_short
-                if (!(r.idf >= 9.313225746154785e-10f && r.idf <= 1073741824.0f)) hg.fast_div = false;
-                if (std::signbit(r.idf) || std::signbit(r.qweight)) hg.signed_in = true;   // a contribution may be -0.0f (see dscore_body)
-            }
-            hg.g.term_count = (uint32_t)dterms.size() - hg.g.term_begin;
-            if ((flags & NS_FLAG_AND) && hg.g.term_count > 255) return fail(ctx, NS_E_INVAL, "AND mode supports at most 255 term refs per (query, segment)");
-            hg.wave = wave_path && hg.g.term_count <= kWaveMaxTerms;
-            // class of the group (auto mode only): which scoring body suits its mix of lists (sweeps on
-            // MI355X, profiles/r01): 1 = one list dominates (the others hold <= 1/32 of its postings): driver
-            // stream with the 64-posting foreign budget; 2 = dense (>= 0.25 postings per doc over >= 2
-            // lists): doc tiles; 0 = driver stream with the 128-posting budget.
-            {
-                const uint64_t rest = hg.cost - hg.cmax;
-                const uint32_t nd = std::max<uint32_t>(segs[sid].n_docs, 1);
-                if (rest * 32 <= hg.cmax) hg.cls = 1;
-                else if (hg.g.term_count >= 2 && hg.cost * 4 >= (uint64_t)nd) hg.cls = 2;
-                else hg.cls = 0;
-                // work estimate in units of one streamed driver posting (measured, profiles/r01): a foreign
-                // posting (claim, accumulate, read back) costs ~10x, a doc-tile posting ~3x
-                hg.work = (ctx->variant != 0) ? hg.cost : (hg.cls == 2 ? hg.cost * kWorkTile : hg.cmax + rest * kWorkForeign);
-            }
-            if (!hg.wave) {
-                hg.g.bounds_off = bounds_total;
-                bounds_total += (uint64_t)(segs[sid].n_tiles + 1) * hg.g.term_count;
-            }
-            postings_total += hg.cost;
-            groups.push_back(hg);
-        }
+    // ---- slices: one per host thread for large batches (below ~1500 queries per thread the hand-over costs more than it saves) ----
+    if (!ctx->prep) ctx->prep = new ns_prep();
+    ns_prep& P = *ctx->prep;
+    unsigned width = 1;
+    if (n_queries >= 3000 && ctx->prep_threads != 1) {
+        unsigned want = ctx->prep_threads ? ctx->prep_threads : std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 8u);
+        width = std::max(1u, std::min<unsigned>(want, n_queries / 1500));
     }
-    qgroup_begin[n_queries] = (uint32_t)groups.size();
+    if (width > 1 && (!P.pool || P.pool->width() < width)) { delete P.pool; P.pool = new ForkJoin(width); }
+    if (P.slices.size() < width) P.slices.resize(width);
+    for (unsigned s = 0; s < width; s++) P.slices[s].reset((uint32_t)((uint64_t)n_queries * s / width), (uint32_t)((uint64_t)n_queries * (s + 1) / width));
+    auto fork = [&](const std::function<void(unsigned)>& fn) {
+        if (width == 1) fn(0); else P.pool->run(width, fn);
+    };
+    const bool want_imp = ctx->use_impacts && auto_mode;
+
+    // ---- phase A: regroup term refs by (query, segment), keeping query-term order inside each group; classify ----
+    fork([&](unsigned si) {
+        PrepSlice& S = P.slices[si];
+        S.all_imp = want_imp;   // stays true while every list met so far has an impact stream built with this idf
+        S.qgroup_begin.reserve(S.q1 - S.q0 + 1);
+        for (uint32_t q = S.q0; q < S.q1; q++) {
+            S.qgroup_begin.push_back((uint32_t)S.groups.size());
+            const ns_query_desc qd = queries[q];
+            if (qd.term_count && !terms) { S.fail_at(q, NS_E_INVAL, "terms is NULL"); break; }
+            S.seg_ids.clear();
+            bool bad = false;
+            for (uint32_t i = 0; i < qd.term_count && !bad; i++) {
+                const ns_term_ref& r = terms[qd.term_begin + i];
+                if (r.seg_id >= ctx->segs.size() || !ctx->segs[r.seg_id]) { S.fail_at(q, NS_E_INVAL, "query %u term %u: unknown segment %u", q, i, r.seg_id); bad = true; break; }
+                const ns_seg* s = ctx->segs[r.seg_id];
+                if (r.byte_off % 8 != 0) { S.fail_at(q, NS_E_INVAL, "query %u term %u: byte_off %llu not a multiple of 8", q, i, (unsigned long long)r.byte_off); bad = true; break; }
+                if (r.byte_off / 8 + r.count > s->n_postings) { S.fail_at(q, NS_E_INVAL, "query %u term %u: list [%llu,+%u) outside segment %u (%llu postings)", q, i, (unsigned long long)(r.byte_off / 8), r.count, r.seg_id, (unsigned long long)s->n_postings); bad = true; break; }
+                if (std::find(S.seg_ids.begin(), S.seg_ids.end(), r.seg_id) == S.seg_ids.end()) S.seg_ids.push_back(r.seg_id);
+            }
+            if (bad) break;
+            std::sort(S.seg_ids.begin(), S.seg_ids.end());   // segments in manifest (id) order, api_engine.cpp:441
+            for (uint32_t sid : S.seg_ids) {
+                HostGroup hg{};
+                hg.fast_div = ctx->segs[sid]->norm_safe;
+                hg.g.term_begin = (uint32_t)S.dterms.size();   // local to the slice until phase B
+                hg.g.seg = sid;
+                hg.query = q;
+                for (uint32_t i = 0; i < qd.term_count; i++) {
+                    const ns_term_ref& r = terms[qd.term_begin + i];
+                    if (r.seg_id != sid) continue;
+                    DevTerm t{};
+                    t.list_off = r.byte_off / 8;
+                    t.count = r.count;
+                    t.idf = r.idf;
+                    t.weight = r.qweight;
+                    t.seg = sid;
+                    S.dterms.push_back(t);
+                    hg.cost += r.count;
+                    hg.cmax = std::max<uint64_t>(hg.cmax, r.count);
+                    if (S.all_imp) {
+                        uint32_t ib; std::memcpy(&ib, &r.idf, 4);
+                        S.all_imp = ctx->segs[sid]->imp_has((uint32_t)(r.byte_off / 8), r.count, ib);
+                    }
+                    // 2^-30 <= idf <= 2^30 (and finite): see ns_div_short
+                    if (!(r.idf >= 9.313225746154785e-10f && r.idf <= 1073741824.0f)) hg.fast_div = false;
+                    if (std::signbit(r.idf) || std::signbit(r.qweight)) hg.signed_in = true;   // a contribution may be -0.0f (see dscore_body)
+                }
+                hg.g.term_count = (uint32_t)S.dterms.size() - hg.g.term_begin;
+                if ((flags & NS_FLAG_AND) && hg.g.term_count > 255) { S.fail_at(q, NS_E_INVAL, "AND mode supports at most 255 term refs per (query, segment)"); bad = true; break; }
+                hg.wave = wave_path && hg.g.term_count <= kWaveMaxTerms;
+                // class of the group (auto mode only): which scoring body suits its mix of lists (sweeps on
+                // MI355X, profiles/r01): 1 = one list dominates (the others hold <= 1/32 of its postings): driver
+                // stream with the 64-posting foreign budget; 2 = dense (>= 0.25 postings per doc over >= 2
+                // lists): doc tiles; 0 = driver stream with the 192-posting budget.
+                {
+                    const uint64_t rest = hg.cost - hg.cmax;
+                    const uint32_t nd = std::max<uint32_t>(segs[sid].n_docs, 1);
+                    if (rest * 32 <= hg.cmax) hg.cls = 1;
+                    else if (hg.g.term_count >= 2 && hg.cost * 4 >= (uint64_t)nd) hg.cls = 2;
+                    else hg.cls = 0;
+                    // work estimate in units of one streamed driver posting (measured, profiles/r01): a foreign
+                    // posting (claim, accumulate, read back) costs ~8x, a doc-tile posting ~2x
+                    hg.work = !auto_mode ? hg.cost : (hg.cls == 2 ? hg.cost * kWorkTile : hg.cmax + rest * kWorkForeign);
+                }
+                if (!hg.wave) {
+                    hg.g.bounds_off = S.bounds_total;   // local; the slice's base is added in phase B
+                    S.bounds_total += (uint64_t)(segs[sid].n_tiles + 1) * hg.g.term_count;
+                }
+                S.postings_total += hg.cost;
+                S.total_work += hg.work;
+                S.groups.push_back(hg);
+            }
+            if (bad) break;
+        }
+        S.qgroup_begin.resize(S.q1 - S.q0 + 1, (uint32_t)S.groups.size());
+    });
+    {
+        const PrepSlice* first = nullptr;
+        for (unsigned s = 0; s < width; s++)
+            if (P.slices[s].err_code != NS_OK && (!first || P.slices[s].err_query < first->err_query)) first = &P.slices[s];
+        if (first) return fail(ctx, first->err_code, "%s", first->err_msg.c_str());
+    }
+    uint64_t bounds_total = 0, postings_total = 0, total_work = 0;
+    uint32_t n_dterms = 0, G = 0;
+    bool all_imp = want_imp;
+    for (unsigned s = 0; s < width; s++) {
+        PrepSlice& S = P.slices[s];
+        S.term_off = n_dterms; S.bounds_off = bounds_total;
+        n_dterms += (uint32_t)S.dterms.size(); G += (uint32_t)S.groups.size();
+        bounds_total += S.bounds_total; postings_total += S.postings_total; total_work += S.total_work;
+        all_imp = all_imp && S.all_imp;
+    }
     if (bounds_total >= (1ull << 32)) return fail(ctx, NS_E_INVAL, "batch too large: %llu boundary entries; split the batch", (unsigned long long)bounds_total);
 
     // ---- work items.  A group is split into doc ranges (a) so that no single worker carries more
@@ -705,126 +895,141 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
     // order is longest-estimated-work first), and (b) so that a small batch still fills the chip.  Partial rows of one query are contiguous; k_merge joins them.
     const uint32_t min_items = ctx->min_items ? ctx->min_items : (uint32_t)std::max(ctx->n_cus, 1) * 24u;
     uint64_t split_postings = ctx->split_postings ? ctx->split_postings
-                              : (ctx->variant != 0 ? kDefaultSplitPostings : (k <= 32 ? kSplitWorkSmallK : kSplitWorkLargeK));
-    if (!ctx->split_postings && ctx->variant == 0) {
+                              : (!auto_mode ? kDefaultSplitPostings : (k <= 32 ? kSplitWorkSmallK : kSplitWorkLargeK));
+    if (!ctx->split_postings && auto_mode) {
         // a small batch: cut finer so that the chip still sees ~100 items per CU (an item of the default size
         // runs 0.3-1.3 ms: with fewer items than wave slots that would be the whole batch's time), but not
         // below ~16 K units, where an item's fixed cost takes over
-        uint64_t total_work = 0;
-        for (const HostGroup& hg : groups) total_work += hg.work;
         const uint64_t fine = total_work / ((uint64_t)std::max(ctx->n_cus, 1) * 96u);
         split_postings = std::min<uint64_t>(split_postings, std::max<uint64_t>(fine, 16384));
     }
-    const uint32_t G = (uint32_t)groups.size();
     uint32_t chunks_per_group = 1;
     if (G > 0 && G < min_items) chunks_per_group = std::min<uint32_t>((min_items + G - 1) / G, 1024u);   // one query alone: 1024 ranges are plenty
-    struct Cost { uint64_t c; uint32_t idx; };
-    std::vector<DevItem> items;
-    std::vector<DevWItem> witems;
-    std::vector<Cost> item_cost, witem_cost;
-    std::vector<uint8_t> witem_cls;
-    std::vector<DevGroup> bgroups;
     std::vector<DevQuery> dq(n_queries);
-    uint32_t n_rows = 0;
-    bool direct = true;
-    for (uint32_t q = 0; q < n_queries; q++) {
-        dq[q].part_begin = n_rows;
-        for (uint32_t gi = qgroup_begin[q]; gi < qgroup_begin[q + 1]; gi++) {
-            const HostGroup& hg = groups[gi];
-            const DevSeg& sg = segs[hg.g.seg];
-            if (sg.n_docs == 0) continue;   // empty segment: nothing to score
-            if (hg.wave) {
-                // thin and tile groups run at a steady rate per posting: fewer, longer items (less per-item set-up,
-                // same balance); groups with dense foreign lists vary more per posting and stay finer
-                const uint64_t sp_ = (ctx->variant == 0 && hg.cls != 0) ? split_postings * 2 : split_postings;
-                uint64_t want = std::max<uint64_t>((hg.work + sp_ - 1) / sp_, chunks_per_group);
-                uint32_t ns = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want, 1), std::min<uint32_t>(sg.n_docs, 4096));
-                for (uint32_t i = 0; i < ns; i++) {
-                    DevWItem it{};
-                    it.query = q;
-                    it.seg = hg.g.seg;
-                    it.term_begin = hg.g.term_begin;
-                    it.term_count = hg.g.term_count;
-                    it.doc_lo = (uint32_t)((uint64_t)sg.n_docs * i / ns);
-                    it.doc_hi = (uint32_t)((uint64_t)sg.n_docs * (i + 1) / ns);
-                    if (it.doc_hi <= it.doc_lo) continue;
-                    it.out_slot = n_rows++;
-                    it.whole = (ns == 1 ? 1u : 0u) | (hg.fast_div ? 8u : 0u) | (hg.signed_in ? 16u : 0u);
-                    {
-                        // launch-order key = estimated run time of the ITEM: its share of the group's work plus what
-                        // every item pays per term regardless of size (window planning, range searches, table set-up)
-                        const uint64_t per_term = hg.cls == 2 ? kItemTermTile : (hg.cls == 1 ? kItemTermThin : kItemTermGeneral);
-                        witem_cost.push_back({hg.work / ns + 1 + (ctx->variant == 0 ? per_term * hg.g.term_count : 0), (uint32_t)witems.size()});
+
+    // ---- phase B: cut the groups into work items (rows numbered inside the slice) ----
+    fork([&](unsigned si) {
+        PrepSlice& S = P.slices[si];
+        for (uint32_t q = S.q0; q < S.q1; q++) {
+            dq[q].part_begin = S.n_rows;
+            for (uint32_t gi = S.qgroup_begin[q - S.q0]; gi < S.qgroup_begin[q - S.q0 + 1]; gi++) {
+                HostGroup& hg = S.groups[gi];
+                hg.g.term_begin += S.term_off;          // global from here on
+                const DevSeg& sg = segs[hg.g.seg];
+                if (sg.n_docs == 0) continue;   // empty segment: nothing to score
+                if (hg.wave) {
+                    // thin and tile groups run at a steady rate per posting: fewer, longer items (less per-item set-up,
+                    // same balance); groups with dense foreign lists vary more per posting and stay finer
+                    const uint64_t sp_ = (auto_mode && hg.cls != 0) ? split_postings * 2 : split_postings;
+                    const uint64_t want = std::max<uint64_t>((hg.work + sp_ - 1) / sp_, chunks_per_group);
+                    const uint32_t ns = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want, 1), std::min<uint32_t>(sg.n_docs, 4096));
+                    // launch-order key = estimated run time of the ITEM: its share of the group's work plus what
+                    // every item pays per term regardless of size (window planning, range searches, table set-up)
+                    const uint64_t per_term = hg.cls == 2 ? kItemTermTile : (hg.cls == 1 ? kItemTermThin : kItemTermGeneral);
+                    const uint64_t key = hg.work / ns + 1 + (auto_mode ? per_term * hg.g.term_count : 0);
+                    const bool wide = auto_mode && hg.g.term_count > 16;
+                    const uint32_t bucket = order_bucket(key);
+                    for (uint32_t i = 0; i < ns; i++) {
+                        DevWItem it{};
+                        it.query = q;
+                        it.seg = hg.g.seg;
+                        it.term_begin = hg.g.term_begin;
+                        it.term_count = hg.g.term_count;
+                        it.doc_lo = (uint32_t)((uint64_t)sg.n_docs * i / ns);
+                        it.doc_hi = (uint32_t)((uint64_t)sg.n_docs * (i + 1) / ns);
+                        if (it.doc_hi <= it.doc_lo) continue;
+                        it.out_slot = S.n_rows++;
+                        it.whole = (ns == 1 ? 1u : 0u) | (hg.fast_div ? 8u : 0u) | (hg.signed_in ? 16u : 0u);
+                        // auto mode: very dense groups take the doc-tile body (bit 1), groups with thin non-driver lists the small foreign budget (bit 2)
+                        if (auto_mode) it.whole |= (hg.cls == 2 ? 2u : 0u) | (hg.cls == 1 ? 4u : 0u);
+                        S.witems.push_back(it);
+                        S.wbucket.push_back((uint16_t)(bucket | (wide ? 0x8000u : 0u)));
+                        S.hist[(wide ? kOrderBuckets : 0) + bucket]++;
                     }
-                    witem_cls.push_back(hg.cls);
-                    witems.push_back(it);
-                }
-            } else {
-                bgroups.push_back(hg.g);
-                uint32_t nt = sg.n_tiles;
-                uint32_t chunks = std::min(chunks_per_group, nt);
-                uint32_t per = (nt + chunks - 1) / chunks;
-                for (uint32_t tb = 0; tb < nt; tb += per) {
-                    DevItem it{};
-                    it.bounds_off = hg.g.bounds_off;
-                    it.query = q;
-                    it.seg = hg.g.seg;
-                    it.term_begin = hg.g.term_begin;
-                    it.term_count = hg.g.term_count;
-                    it.tile_begin = tb;
-                    it.tile_end = std::min(nt, tb + per);
-                    it.out_slot = n_rows++;
-                    item_cost.push_back({hg.cost * (it.tile_end - it.tile_begin) / nt + 1, (uint32_t)items.size()});
-                    items.push_back(it);
+                } else {
+                    DevGroup g = hg.g;
+                    g.bounds_off += S.bounds_off;
+                    S.bgroups.push_back(g);
+                    const uint32_t nt = sg.n_tiles;
+                    const uint32_t chunks = std::min(chunks_per_group, nt);
+                    const uint32_t per = (nt + chunks - 1) / chunks;
+                    for (uint32_t tb = 0; tb < nt; tb += per) {
+                        DevItem it{};
+                        it.bounds_off = g.bounds_off;
+                        it.query = q;
+                        it.seg = g.seg;
+                        it.term_begin = g.term_begin;
+                        it.term_count = g.term_count;
+                        it.tile_begin = tb;
+                        it.tile_end = std::min(nt, tb + per);
+                        it.out_slot = S.n_rows++;
+                        S.item_cost.push_back(hg.cost * (it.tile_end - it.tile_begin) / nt + 1);
+                        S.items.push_back(it);
+                    }
                 }
             }
+            dq[q].part_count = S.n_rows - dq[q].part_begin;
+            if (dq[q].part_count != 1) S.direct = false;
         }
-        dq[q].part_count = n_rows - dq[q].part_begin;
-        if (dq[q].part_count != 1) direct = false;
+    });
+    uint32_t n_rows = 0, n_witems = 0, n_items = 0, n_bgroups = 0;
+    bool direct = n_queries > 0;
+    for (unsigned s = 0; s < width; s++) {
+        PrepSlice& S = P.slices[s];
+        S.row_off = n_rows; S.item_off = n_items; S.bgroup_off = n_bgroups;
+        n_rows += S.n_rows; n_witems += (uint32_t)S.witems.size(); n_items += (uint32_t)S.items.size(); n_bgroups += (uint32_t)S.bgroups.size();
+        direct = direct && S.direct;
     }
-    if (n_queries == 0) direct = false;
-    if (direct) {
-        for (auto& it : items) it.out_slot = it.query;
-        for (auto& it : witems) it.out_slot = it.query;
-    }
-
-    // longest-processing-time-first launch order (workgroups are dispatched in blockIdx order)
-    auto by_cost = [](const Cost& a, const Cost& b) { return a.c > b.c; };
-    std::stable_sort(item_cost.begin(), item_cost.end(), by_cost);
-    std::stable_sort(witem_cost.begin(), witem_cost.end(), by_cost);
-    std::vector<DevItem> sorted_items(items.size());
-    std::vector<DevWItem> sorted_witems(witems.size());
-    for (size_t i = 0; i < items.size(); i++) sorted_items[i] = items[item_cost[i].idx];
-    for (size_t i = 0; i < witems.size(); i++) sorted_witems[i] = witems[witem_cost[i].idx];
-    uint32_t n_class[3] = {0, 0, 0};   // [0] = items of groups with <= 16 terms (first in d_witems), [1] = the rest
-    if (ctx->variant == 0) {
-        // auto mode: tag very dense groups for the doc-tile body (bit 1 of DevWItem::whole) and groups
-        // with thin non-driver lists for the small foreign budget (bit 2); groups of <= 16 terms first
-        std::vector<DevWItem> narrow, wide;
-        for (size_t i = 0; i < witems.size(); i++) {
-            const uint8_t c = witem_cls[witem_cost[i].idx];
-            DevWItem it = sorted_witems[i];
-            if (c == 2) it.whole |= 2u;
-            if (c == 1) it.whole |= 4u;
-            (it.term_count <= 16 ? narrow : wide).push_back(it);
+    // launch order of the wave items: narrow (<= 16 terms) before wide, longest estimated run time first, ties in query order
+    uint32_t n_class[3] = {0, 0, 0};
+    {
+        uint32_t pos = 0;
+        for (uint32_t half = 0; half < 2; half++) {
+            for (uint32_t bkt = 0; bkt < kOrderBuckets; bkt++)
+                for (unsigned s = 0; s < width; s++) {
+                    P.slices[s].start[half * kOrderBuckets + bkt] = pos;
+                    pos += P.slices[s].hist[half * kOrderBuckets + bkt];
+                }
+            if (half == 0) n_class[0] = pos;
         }
-        n_class[0] = (uint32_t)narrow.size();
-        n_class[1] = (uint32_t)wide.size();
-        sorted_witems = narrow;
-        sorted_witems.insert(sorted_witems.end(), wide.begin(), wide.end());
+        n_class[1] = pos - n_class[0];
+        if (!auto_mode) { n_class[0] = n_class[1] = 0; }
+    }
+    // the workgroup-kernel items (fallback path: few): longest first, serially
+    std::vector<DevItem> sorted_items;
+    if (n_items) {
+        struct Cost { uint64_t c; uint32_t slice, idx; };
+        std::vector<Cost> ic;
+        ic.reserve(n_items);
+        for (unsigned s = 0; s < width; s++)
+            for (uint32_t i = 0; i < P.slices[s].items.size(); i++) ic.push_back({P.slices[s].item_cost[i], s, i});
+        std::stable_sort(ic.begin(), ic.end(), [](const Cost& a, const Cost& b) { return a.c > b.c; });
+        sorted_items.resize(n_items);
+        for (uint32_t i = 0; i < n_items; i++) {
+            DevItem it = P.slices[ic[i].slice].items[ic[i].idx];
+            it.out_slot = direct ? it.query : it.out_slot + P.slices[ic[i].slice].row_off;
+            sorted_items[i] = it;
+        }
     }
 
     ns_batch* b = new ns_batch();
     b->ctx = ctx;
     b->Q = n_queries; b->K = k; b->flags = flags;
     b->variant = ctx->variant; b->tile_docs = tile_docs; b->hb = vd.hb;
-    b->n_items = (uint32_t)items.size(); b->n_witems = (uint32_t)witems.size();
-    b->n_bgroups = (uint32_t)bgroups.size(); b->n_terms = (uint32_t)dterms.size();
+    b->n_items = n_items; b->n_witems = n_witems;
+    b->n_bgroups = n_bgroups; b->n_terms = n_dterms;
     for (int c = 0; c < 3; c++) b->n_class[c] = n_class[c];
     b->n_parts = direct ? 0 : n_rows;
     b->postings = postings_total;
     b->direct = direct;
     b->imp = all_imp && postings_total > 0;
+
+    // queries cut into many partial rows: joined by k_merge_wide, one workgroup each
+    std::vector<uint32_t> wide_q;
+    if (!direct)
+        for (uint32_t q = 0; q < n_queries; q++)
+            if (merge_is_wide(dq[q].part_count, k)) wide_q.push_back(q);
+    b->n_wide_q = (uint32_t)wide_q.size();
 
     // One device block per batch: [descriptors, uploaded in one copy][scratch][hits | nhits | found, fetched in one copy]
     hipError_t e = hipSuccess;
@@ -832,17 +1037,12 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
     size_t off = 0;
     auto place = [&](size_t bytes) { const size_t o = off; off = (off + std::max<size_t>(bytes, 1) + 255) & ~(size_t)255; return o; };
     const size_t Qn = std::max<uint32_t>(n_queries, 1), Pn = std::max<uint32_t>(b->n_parts, 1);
-    const size_t o_items = place(sorted_items.size() * sizeof(sorted_items[0]));
-    const size_t o_witems = place(sorted_witems.size() * sizeof(sorted_witems[0]));
-    const size_t o_terms = place(dterms.size() * sizeof(dterms[0]));
-    const size_t o_groups = place(bgroups.size() * sizeof(bgroups[0]));
+    const size_t o_items = place((size_t)n_items * sizeof(DevItem));
+    const size_t o_witems = place((size_t)n_witems * sizeof(DevWItem));
+    const size_t o_terms = place((size_t)n_dterms * sizeof(DevTerm));
+    const size_t o_groups = place((size_t)n_bgroups * sizeof(DevGroup));
     const size_t o_queries = place(dq.size() * sizeof(dq[0]));
     const size_t o_segs = place(segs.size() * sizeof(segs[0]));
-    std::vector<uint32_t> wide_q;   // queries cut into many partial rows: joined by k_merge_wide, one workgroup each
-    if (!direct)
-        for (uint32_t q = 0; q < n_queries; q++)
-            if (merge_is_wide(dq[q].part_count, k)) wide_q.push_back(q);
-    b->n_wide_q = (uint32_t)wide_q.size();
     const size_t o_wideq = place(wide_q.size() * 4);
     const size_t up_bytes = off;
     const size_t o_bounds = place(bounds_total * 4);
@@ -904,23 +1104,32 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
         const size_t cap = std::max<size_t>(up_bytes + up_bytes / 2, 1 << 16);
         if (hipHostMalloc(&ctx->h_up, cap, hipHostMallocDefault) == hipSuccess) ctx->h_up_cap = cap;
         else { ctx->h_up = nullptr; (void)hipGetLastError(); }
-        if (!ctx->up_done) chk(hipEventCreateWithFlags(&ctx->up_done, hipEventDisableTiming));
     }
+    if (e == hipSuccess && !ctx->up_done) chk(hipEventCreateWithFlags(&ctx->up_done, hipEventDisableTiming));
     if (e == hipSuccess) {
+        // ---- phase C: the descriptors go straight into the pinned staging buffer (or, for a batch too large for it, into
+        // a host vector that is copied array by array), wave items at their place in the launch order ----
         const bool staged = ctx->h_up_cap >= up_bytes && ctx->up_done;
-        char* hb = staged ? (char*)ctx->h_up : nullptr;
-        auto put = [&](size_t o, const void* src, size_t bytes) {
-            if (!bytes) return;
-            if (staged) std::memcpy(hb + o, src, bytes);
-            else chk(hipMemcpyAsync(base + o, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-        };
-        put(o_items, sorted_items.data(), sorted_items.size() * sizeof(sorted_items[0]));
-        put(o_witems, sorted_witems.data(), sorted_witems.size() * sizeof(sorted_witems[0]));
-        put(o_terms, dterms.data(), dterms.size() * sizeof(dterms[0]));
-        put(o_groups, bgroups.data(), bgroups.size() * sizeof(bgroups[0]));
-        put(o_queries, dq.data(), dq.size() * sizeof(dq[0]));
-        put(o_segs, segs.data(), segs.size() * sizeof(segs[0]));
-        put(o_wideq, wide_q.data(), wide_q.size() * 4);
+        std::vector<char> unstaged;
+        if (!staged) unstaged.resize(up_bytes);
+        char* hb = staged ? (char*)ctx->h_up : unstaged.data();
+        fork([&](unsigned si) {
+            PrepSlice& S = P.slices[si];
+            DevWItem* wdst = (DevWItem*)(hb + o_witems);
+            for (size_t i = 0; i < S.witems.size(); i++) {
+                DevWItem it = S.witems[i];
+                it.out_slot = direct ? it.query : it.out_slot + S.row_off;
+                const uint32_t bk = S.wbucket[i];
+                wdst[S.start[((bk & 0x8000u) ? kOrderBuckets : 0) + (bk & 0x7FFFu)]++] = it;
+            }
+            if (!S.dterms.empty()) std::memcpy(hb + o_terms + (size_t)S.term_off * sizeof(DevTerm), S.dterms.data(), S.dterms.size() * sizeof(DevTerm));
+            if (!S.bgroups.empty()) std::memcpy(hb + o_groups + (size_t)S.bgroup_off * sizeof(DevGroup), S.bgroups.data(), S.bgroups.size() * sizeof(DevGroup));
+            for (uint32_t q = S.q0; q < S.q1; q++) dq[q].part_begin += S.row_off;
+            if (S.q1 > S.q0) std::memcpy(hb + o_queries + (size_t)S.q0 * sizeof(DevQuery), dq.data() + S.q0, (size_t)(S.q1 - S.q0) * sizeof(DevQuery));
+        });
+        if (n_items) std::memcpy(hb + o_items, sorted_items.data(), (size_t)n_items * sizeof(DevItem));
+        if (!segs.empty()) std::memcpy(hb + o_segs, segs.data(), segs.size() * sizeof(segs[0]));
+        if (!wide_q.empty()) std::memcpy(hb + o_wideq, wide_q.data(), wide_q.size() * 4);
         if (staged) {
             // a small upload is pulled by a kernel (the pinned buffer is device-addressable): a DMA-engine copy
             // followed by a kernel costs ~11 us of cross-engine hand-over, more than the copy itself
@@ -932,7 +1141,8 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
             chk(hipEventRecord(ctx->up_done, ctx->stream));
             if (e == hipSuccess) ctx->up_busy = true;
         } else {
-            chk(hipStreamSynchronize(ctx->stream));   // the copies read host vectors that die with this call
+            chk(hipMemcpyAsync(base, hb, up_bytes, hipMemcpyHostToDevice, ctx->stream));
+            chk(hipStreamSynchronize(ctx->stream));   // the copy reads a host vector that dies with this call
         }
     }
     if (e != hipSuccess) {
@@ -953,9 +1163,10 @@ extern "C" int ns_batch_bind_outputs(ns_batch* b, void* d_hits, void* d_nhits, v
     return NS_OK;
 }
 
-extern "C" int ns_batch_run(ns_batch* b, int timed) {
+extern "C" int ns_batch_run(ns_batch* b, int run_flags) {
     if (!b) return NS_E_INVAL;
     ns_ctx* ctx = b->ctx;
+    const int timed = run_flags & NS_RUN_TIMED;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const bool and_mode = (b->flags & NS_FLAG_AND) != 0;
@@ -1037,14 +1248,50 @@ extern "C" int ns_batch_run(ns_batch* b, int timed) {
     if (timed) HIPCHK(ctx, hipEventRecord(ev[3], st));
     HIPCHK(ctx, hipGetLastError());
     b->ran = true;
+    b->done_recorded = false;
+    if (run_flags & NS_RUN_FETCH) {
+        const bool own_outputs = b->o_hits == b->d_hits && b->o_nhits == b->d_nhits && b->o_found == b->d_found;
+        if (!own_outputs) return fail(ctx, NS_E_STATE, "NS_RUN_FETCH: the batch writes into caller-bound device buffers (ns_batch_bind_outputs); there is nothing to fetch");
+        if (b->Q && ctx->down_owner != b) {   // (a small batch that owns h_down already has its results in host memory)
+            if (b->down_slot < 0) {
+                int slot = -1;
+                for (size_t i = 0; i < ctx->down_slots.size(); i++)
+                    if (!ctx->down_slots[i].busy && ctx->down_slots[i].cap >= b->out_span) { slot = (int)i; break; }
+                if (slot < 0) {
+                    for (size_t i = 0; i < ctx->down_slots.size() && slot < 0; i++)
+                        if (!ctx->down_slots[i].busy) {   // grow an idle slot
+                            if (ctx->down_slots[i].p) (void)hipHostFree(ctx->down_slots[i].p);
+                            ctx->down_slots[i] = ns_ctx::DownSlot{};
+                            slot = (int)i;
+                        }
+                    if (slot < 0) {
+                        if (ctx->down_slots.size() >= 8) return fail(ctx, NS_E_STATE, "NS_RUN_FETCH: more than 8 batches between run and fetch");
+                        ctx->down_slots.emplace_back();
+                        slot = (int)ctx->down_slots.size() - 1;
+                    }
+                    const size_t cap = std::max<size_t>(b->out_span + b->out_span / 4, 1 << 16);
+                    if (hipHostMalloc(&ctx->down_slots[(size_t)slot].p, cap, hipHostMallocDefault) != hipSuccess) {
+                        ctx->down_slots[(size_t)slot].p = nullptr;
+                        (void)hipGetLastError();
+                        return fail(ctx, NS_E_NOMEM, "NS_RUN_FETCH: pinned result buffer of %zu bytes", cap);
+                    }
+                    ctx->down_slots[(size_t)slot].cap = cap;
+                }
+                ctx->down_slots[(size_t)slot].busy = true;
+                b->down_slot = slot;
+            }
+            HIPCHK(ctx, hipMemcpyAsync(ctx->down_slots[(size_t)b->down_slot].p, b->d_hits, b->out_span, hipMemcpyDeviceToHost, st));
+        }
+        if (!b->done) HIPCHK(ctx, hipEventCreateWithFlags(&b->done, hipEventDisableTiming));
+        HIPCHK(ctx, hipEventRecord(b->done, st));
+        b->done_recorded = true;
+    }
     return NS_OK;
 }
 
-extern "C" int ns_batch_sync(ns_batch* b) {
-    if (!b) return NS_E_INVAL;
+// reads the HIP-event timings of the runs since the last call (all of them lie before the point the caller has waited for)
+static int batch_collect_timings(ns_batch* b) {
     ns_ctx* ctx = b->ctx;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (size_t i = 0; i + 4 <= b->ev_pending; i += 4) {
         HIPCHK(ctx, hipEventElapsedTime(&b->last_score_ms, b->ev_pool[i + 1], b->ev_pool[i + 2]));
         HIPCHK(ctx, hipEventElapsedTime(&b->last_total_ms, b->ev_pool[i], b->ev_pool[i + 3]));
@@ -1056,6 +1303,14 @@ extern "C" int ns_batch_sync(ns_batch* b) {
     return NS_OK;
 }
 
+extern "C" int ns_batch_sync(ns_batch* b) {
+    if (!b) return NS_E_INVAL;
+    ns_ctx* ctx = b->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return batch_collect_timings(b);
+}
+
 extern "C" int ns_batch_fetch(ns_batch* b, ns_hit* hits_out, uint32_t* nhits_out, uint64_t* found_out) {
     if (!b) return NS_E_INVAL;
     ns_ctx* ctx = b->ctx;
@@ -1063,6 +1318,18 @@ extern "C" int ns_batch_fetch(ns_batch* b, ns_hit* hits_out, uint32_t* nhits_out
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const bool own_outputs = b->o_hits == b->d_hits && b->o_nhits == b->d_nhits && b->o_found == b->d_found;
+    if (b->done_recorded && own_outputs) {   // NS_RUN_FETCH: wait for this batch alone; its results are in (or on their way to) pinned host memory
+        HIPCHK(ctx, hipEventSynchronize(b->done));
+        int rc = batch_collect_timings(b);
+        if (rc != NS_OK) return rc;
+        if (b->Q) {
+            const char* h = (ctx->down_owner == b) ? (const char*)ctx->h_down : (const char*)ctx->down_slots[(size_t)b->down_slot].p;
+            if (hits_out) std::memcpy(hits_out, h, (size_t)b->Q * b->K * sizeof(Hit));
+            if (nhits_out) std::memcpy(nhits_out, h + b->off_nhits, (size_t)b->Q * 4);
+            if (found_out) std::memcpy(found_out, h + b->off_found, (size_t)b->Q * 8);
+        }
+        return NS_OK;
+    }
     if (b->Q && own_outputs && ctx->down_owner == b) {   // the results are already in host memory
         int rc = ns_batch_sync(b);
         if (rc != NS_OK) return rc;

@@ -54,7 +54,7 @@ HIP_SYMBOLS = [
     "ns_ctx_create", "ns_ctx_destroy", "ns_ctx_set_stream", "ns_last_error", "ns_device_name",
     "ns_segment_upload", "ns_segment_release", "ns_segment_upload_begin", "ns_segment_upload_append", "ns_segment_upload_end", "ns_search_batch", "ns_batch_prepare",
     "ns_batch_bind_outputs", "ns_batch_run", "ns_batch_sync", "ns_batch_fetch", "ns_batch_get_info",
-    "ns_batch_destroy", "ns_set_tuning", "ns_segment_build_impacts", "ns_ctx_use_impacts",
+    "ns_batch_destroy", "ns_set_tuning", "ns_segment_build_impacts", "ns_ctx_use_impacts", "ns_ctx_set_host_threads",
     "ns_invert_forward", "ns_merge_rank_rows", "ns_sem_upload", "ns_sem_release", "ns_sem_topk",
 ]
 HOST_SYMBOLS = [
@@ -94,6 +94,7 @@ def hip_lib():
         L.ns_segment_upload_end.argtypes = [vp, vp]
         L.ns_segment_build_impacts.argtypes = [vp, vp, vp, vp, vp, u32]
         L.ns_ctx_use_impacts.argtypes = [vp, i32]
+        L.ns_ctx_set_host_threads.argtypes = [vp, u32]
         L.ns_sem_upload.argtypes = [vp, vp, u32, u32, C.POINTER(vp)]
         L.ns_sem_release.argtypes = [vp, vp]
         L.ns_sem_topk.argtypes = [vp, vp, vp, u32, u32, C.c_float, vp, vp, vp, vp, vp, vp]
@@ -202,8 +203,10 @@ class Batch:
         if rc != NS_OK:
             raise RuntimeError("ns_batch_bind_outputs failed")
 
-    def run(self, timed=False):
-        rc = hip_lib().ns_batch_run(self.h, int(timed))
+    def run(self, timed=False, fetch=False):
+        """fetch=True (NS_RUN_FETCH): the results' copy to pinned host memory rides behind the kernels and fetch()
+        waits for this batch only — batches can then overlap on one ctx."""
+        rc = hip_lib().ns_batch_run(self.h, int(bool(timed)) | (2 if fetch else 0))
         if rc != NS_OK:
             raise RuntimeError(f"ns_batch_run failed rc={rc}")
 
@@ -220,6 +223,12 @@ class Batch:
         if rc != NS_OK:
             raise RuntimeError(f"ns_batch_fetch failed rc={rc}")
         return hits, nhits, found
+
+    def fetch_into(self, hits, nhits, found):
+        """fetch() into caller-owned arrays (HIT_DTYPE [Q, K], uint32 [Q], uint64 [Q]): no allocation per batch."""
+        rc = hip_lib().ns_batch_fetch(self.h, hits.ctypes.data, nhits.ctypes.data, found.ctypes.data)
+        if rc != NS_OK:
+            raise RuntimeError(f"ns_batch_fetch failed rc={rc}")
 
     def info(self):
         inf = NsBatchInfo()
@@ -433,6 +442,45 @@ def invert_segment(seg_dir, device=0):
 
 def u64_():
     return C.c_uint64()
+
+
+def prepare_raw(ctx, qd, refs, k, flags=NS_FLAG_OR):
+    """ns_batch_prepare on descriptor arrays that are already in the C-ABI's layout (numpy QDESC_DTYPE / TERM_DTYPE)."""
+    b = C.c_void_p()
+    rc = hip_lib().ns_batch_prepare(ctx, qd.ctypes.data, refs.ctypes.data if len(refs) else None, len(qd), int(k), flags, C.byref(b))
+    if rc != NS_OK:
+        raise RuntimeError("ns_batch_prepare: " + hip_lib().ns_last_error(ctx).decode())
+    return Batch(b, len(qd), int(k))
+
+
+def pipelined_search(ctx, batches, k, flags=NS_FLAG_OR, out=None, timed=False):
+    """Host -> host search of a sequence of batches [(qd, refs), ...] with two batches in flight on the one ctx:
+    while the device scores batch i the host prepares and uploads batch i+1, and batch i's results are fetched as
+    soon as they have landed (NS_RUN_FETCH).  Yields (hits, nhits, found, info) per batch, in order.  `out`: optional
+    list of preallocated (hits, nhits, found) triples, reused round-robin (at least 2)."""
+    def bufs(i, Q):
+        if out is not None:
+            return out[i % len(out)]
+        return (np.empty((Q, k), dtype=HIT_DTYPE), np.empty(Q, dtype=np.uint32), np.empty(Q, dtype=np.uint64))
+    prev = None
+    for i, (qd, refs) in enumerate(batches):
+        b = prepare_raw(ctx, qd, refs, k, flags)
+        b.run(timed=timed, fetch=True)
+        if prev is not None:
+            pb, pi = prev
+            o = bufs(pi, pb.Q)
+            pb.fetch_into(*o)
+            inf = pb.info()
+            pb.close()
+            yield o + (inf,)
+        prev = (b, i)
+    if prev is not None:
+        pb, pi = prev
+        o = bufs(pi, pb.Q)
+        pb.fetch_into(*o)
+        inf = pb.info()
+        pb.close()
+        yield o + (inf,)
 
 
 def search_batch_raw(ctx, qd, refs, k, flags=NS_FLAG_OR):

@@ -244,6 +244,41 @@ def test_reload_streams_inverted_files_without_a_host_copy(index_factory):
         warm.close(); host_only.close(); dev.close()
 
 
+def test_overlapping_batches_and_host_thread_count(index_factory):
+    """prepare(i+1) || run(i) || fetch(i-1) on ONE ctx (NS_RUN_FETCH: per-batch completion events and
+    pinned result slots).  Six different batches go through the pipeline with two in flight; every one must equal
+    the oracle bit for bit, whatever number of host threads prepared it (1, automatic, 5), and destroying batch i
+    while batch i+1 runs must not disturb i+1."""
+    d, _ = index_factory(2, 60_000, 65536, 1337, False)
+    eng, ora = nsbind.Engine(d, 0), orc.Oracle(d)
+    L = nsbind.hip_lib()
+    try:
+        sets = [workloads.cfg5_queries(3500 + 211 * i, 77 + i) for i in range(4)] + [workloads.cfg3_queries(300, 5), ["covid"]]
+        descs = []
+        for qs in sets:
+            qd, refs, usable = eng.build_refs(qs)
+            assert usable.all()
+            descs.append((qd, refs))
+        want = [ora.search_batch(qs, 10, threads=16) for qs in sets]
+        for threads in (1, 0, 5):
+            assert L.ns_ctx_set_host_threads(eng.ctx, threads) == 0
+            got = list(nsbind.pipelined_search(eng.ctx, descs, 10, timed=True))
+            assert len(got) == len(sets)
+            for qs, (hits, nhits, found, inf), w in zip(sets, got, want):
+                assert inf.timed_runs == 1 and inf.n_queries == len(qs)
+                assert_same((hits, nhits, found, np.ones(len(qs), np.uint8)), w, qs, f"pipelined, host threads {threads}")
+        # the same through preallocated, reused output buffers (what bench.py does)
+        k = 10
+        out = [(np.empty((4400, k), dtype=nsbind.HIT_DTYPE), np.empty(4400, np.uint32), np.empty(4400, np.uint64)) for _ in range(2)]
+        for i, (hits, nhits, found, inf) in enumerate(nsbind.pipelined_search(eng.ctx, descs[:4], k, out=out)):
+            Q = len(sets[i])
+            assert_same((hits[:Q].copy(), nhits[:Q].copy(), found[:Q].copy(), np.ones(Q, np.uint8)), want[i], sets[i], "pipelined, reused buffers")
+        L.ns_ctx_set_host_threads(eng.ctx, 0)
+    finally:
+        eng.close()
+        ora.close()
+
+
 def test_and_extension_matches_derived_oracle(engines):
     g, eng, ora = engines("mid1")
     queries = workloads.cfg2_queries(64, 2002, g["params"]["vocab"]) + ["covid virus", "covid zzzzunknown", "covid covid virus"]

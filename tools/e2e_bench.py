@@ -20,6 +20,26 @@ for rep in range(3):
     t6 = time.perf_counter(); eng.search_batch(qs, 10); t7 = time.perf_counter()
     print(f"rep {rep}: query prep (tokenise+lexicon+idf) {1e3*(t1-t0):.1f} ms | ns_search_batch (host->host) {1e3*(t2-t1):.1f} ms = {Q/(t2-t1):.0f} q/s | "
           f"prepare(incl. query prep) {1e3*(t3-t2):.1f} ms, run {1e3*(t4-t3):.2f} ms, fetch {1e3*(t5-t4):.2f} ms | facade search_batch {1e3*(t7-t6):.1f} ms = {Q/(t7-t6):.0f} q/s")
+# pipelined host -> host at the C-ABI (what bench.py reports as `value`): descriptors in host memory in, results in host
+# memory out, two batches in flight on the one ctx: prepare(i+1) || run(i) || fetch(i-1)
+import numpy as np  # noqa: E402
+L = nsbind.hip_lib()
+qd, refs, usable = eng.build_refs(qs)
+out = [(np.empty((Q, 10), dtype=nsbind.HIT_DTYPE), np.empty(Q, np.uint32), np.empty(Q, np.uint64)) for _ in range(2)]
+for threads in (1, 2, 4, 8, 0):
+    L.ns_ctx_set_host_threads(eng.ctx, threads)
+    t_prep = []
+    for _ in range(5):
+        t0 = time.perf_counter(); b = nsbind.prepare_raw(eng.ctx, qd, refs, 10); t_prep.append(time.perf_counter() - t0); b.close()
+    n = 24
+    for _ in nsbind.pipelined_search(eng.ctx, [(qd, refs)] * 4, 10, out=out):
+        pass
+    t0 = time.perf_counter()
+    for _ in nsbind.pipelined_search(eng.ctx, [(qd, refs)] * n, 10, out=out):
+        pass
+    dt = time.perf_counter() - t0
+    print(f"host threads {threads or 'auto'}: ns_batch_prepare alone {1e3 * min(t_prep):.2f} ms (best of 5) | pipelined host->host {1e3 * dt / n:.2f} ms per batch = {Q * n / dt:.0f} q/s")
+L.ns_ctx_set_host_threads(eng.ctx, 0)
 # query TEXT in -> /api/search JSON bodies out (result assembly incl. metadata.csv decoration when the file is there)
 import workloads as _w  # noqa: E402
 with open(os.path.join(idx, "metadata.csv"), "wb") as f:
