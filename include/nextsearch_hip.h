@@ -129,6 +129,11 @@ int ns_segment_upload_end(ns_ctx* ctx, ns_seg* seg);
  * not overlap.  May be called again to add lists or to replace a list's idf. */
 int ns_segment_build_impacts(ns_ctx* ctx, ns_seg* seg, const uint64_t* byte_off, const uint32_t* counts,
                              const float* idfs, uint32_t n_lists);
+/* on != 0: batches prepared from now on alternate between the ctx's stream and a second one, so that the first work
+ * items of batch i+1 fill the wave slots the draining tail of batch i leaves idle (matters most for small batches:
+ * a 2048-query shard of a strong-scaled batch).  Only with the ctx's own stream (ignored after ns_ctx_set_stream with
+ * a caller's stream).  A batch's upload, kernels and result copy all stay on the one stream it was prepared on. */
+int ns_ctx_set_overlap(ns_ctx* ctx, int on);
 /* Host threads ns_batch_prepare may use for a large batch (regrouping the term refs, cutting work items, writing the
  * descriptors): 0 = automatic (up to 8, one per ~1500 queries), 1 = the calling thread only.  The prepared batch — every
  * descriptor byte and the launch order — does not depend on this number. */

@@ -130,6 +130,10 @@ struct ns_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    // Batches alternate between the ctx's stream and this second one when overlap is on (ns_ctx_set_overlap): the
+    // head of batch i+1 then fills the wave slots that the draining tail of batch i leaves idle.
+    hipStream_t alt_stream = nullptr;
+    bool overlap = false, flip = false;
     std::string err;
     std::string devname;
     int n_cus = 0;
@@ -265,6 +269,7 @@ extern "C" int ns_ctx_create(int device, ns_ctx** out) {
         return rc;
     }
     ctx->stream = ctx->own_stream;
+    if (hipStreamCreateWithFlags(&ctx->alt_stream, hipStreamNonBlocking) != hipSuccess) { ctx->alt_stream = nullptr; (void)hipGetLastError(); }
     *out = ctx;
     return NS_OK;
 }
@@ -273,6 +278,7 @@ extern "C" void ns_ctx_destroy(ns_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->alt_stream) (void)hipStreamSynchronize(ctx->alt_stream);
     for (ns_seg* s : ctx->segs) {
         if (!s) continue;
         seg_free_device_fwd(s);
@@ -284,6 +290,7 @@ extern "C" void ns_ctx_destroy(ns_ctx* ctx) {
     for (auto& ds : ctx->down_slots) if (ds.p) (void)hipHostFree(ds.p);
     if (ctx->up_done) (void)hipEventDestroy(ctx->up_done);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->alt_stream) (void)hipStreamDestroy(ctx->alt_stream);
     prep_free(ctx->prep);
     delete ctx;
 }
@@ -454,6 +461,7 @@ extern "C" int ns_segment_release(ns_ctx* ctx, ns_seg* seg) {
     if (!seg->pending && (seg->id >= ctx->segs.size() || ctx->segs[seg->id] != seg)) return fail(ctx, NS_E_INVAL, "segment does not belong to this ctx");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->alt_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->alt_stream));
     seg_free_staging(seg);
     seg_free_device(seg);
     if (!seg->pending) ctx->segs[seg->id] = nullptr;
@@ -548,6 +556,13 @@ extern "C" int ns_segment_build_impacts(ns_ctx* ctx, ns_seg* seg, const uint64_t
     return NS_OK;
 }
 
+extern "C" int ns_ctx_set_overlap(ns_ctx* ctx, int on) {
+    if (!ctx) return NS_E_INVAL;
+    if (on && !ctx->alt_stream) return fail(ctx, NS_E_HIP, "ns_ctx_set_overlap: the second stream could not be created");
+    ctx->overlap = on != 0;
+    return NS_OK;
+}
+
 extern "C" int ns_ctx_set_host_threads(ns_ctx* ctx, uint32_t n) {
     if (!ctx) return NS_E_INVAL;
     if (n > 64) return fail(ctx, NS_E_INVAL, "ns_ctx_set_host_threads: %u threads (at most 64)", n);
@@ -606,6 +621,7 @@ struct ns_batch {
     std::vector<std::pair<void*, size_t>> blocks;   // every device block of this batch (returned to the ctx pool on destroy)
     // pipelined use (NS_RUN_FETCH): the results' D2H copy into a pinned slot of the ctx is enqueued right behind the
     // kernels and `done` is recorded after it, so that fetch / destroy wait for THIS batch only, not for the stream
+    hipStream_t st = nullptr;  // the stream all of this batch's work goes to (the ctx's, or its second one when overlap is on)
     hipEvent_t done = nullptr;
     bool done_recorded = false;
     int down_slot = -1;        // index into ns_ctx::down_slots while a D2H copy is pending or unread
@@ -663,7 +679,7 @@ extern "C" void ns_batch_destroy(ns_batch* b) {
     // nothing of THIS batch may still be in flight when its blocks go back to the pool; later batches on the same
     // stream are none of its business (a pipelined caller destroys batch i while batch i+1 runs)
     if (b->done_recorded) (void)hipEventSynchronize(b->done);
-    else (void)hipStreamSynchronize(b->ctx->stream);
+    else (void)hipStreamSynchronize(b->st);
     if (b->ctx->down_owner == b) b->ctx->down_owner = nullptr;
     if (b->down_slot >= 0) b->ctx->down_slots[(size_t)b->down_slot].busy = false;
     for (auto& blk : b->blocks) pool_free(b->ctx, blk.first, blk.second);
@@ -1014,6 +1030,11 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
 
     ns_batch* b = new ns_batch();
     b->ctx = ctx;
+    b->st = ctx->stream;
+    if (ctx->overlap && ctx->stream == ctx->own_stream && ctx->alt_stream) {   // (an externally owned stream is never second-guessed)
+        ctx->flip = !ctx->flip;
+        if (ctx->flip) b->st = ctx->alt_stream;
+    }
     b->Q = n_queries; b->K = k; b->flags = flags;
     b->variant = ctx->variant; b->tile_docs = tile_docs; b->hb = vd.hb;
     b->n_items = n_items; b->n_witems = n_witems;
@@ -1134,15 +1155,15 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
             // a small upload is pulled by a kernel (the pinned buffer is device-addressable): a DMA-engine copy
             // followed by a kernel costs ~11 us of cross-engine hand-over, more than the copy itself
             if (up_bytes <= kPullUploadBytes)
-                hipLaunchKernelGGL(k_pull, dim3((uint32_t)((up_bytes / 16 + 255) / 256)), dim3(256), 0, ctx->stream,
+                hipLaunchKernelGGL(k_pull, dim3((uint32_t)((up_bytes / 16 + 255) / 256)), dim3(256), 0, b->st,
                                    (uint4*)base, (const uint4*)hb, (uint32_t)(up_bytes / 16));
             else
-                chk(hipMemcpyAsync(base, hb, up_bytes, hipMemcpyHostToDevice, ctx->stream));
-            chk(hipEventRecord(ctx->up_done, ctx->stream));
+                chk(hipMemcpyAsync(base, hb, up_bytes, hipMemcpyHostToDevice, b->st));
+            chk(hipEventRecord(ctx->up_done, b->st));
             if (e == hipSuccess) ctx->up_busy = true;
         } else {
-            chk(hipMemcpyAsync(base, hb, up_bytes, hipMemcpyHostToDevice, ctx->stream));
-            chk(hipStreamSynchronize(ctx->stream));   // the copy reads a host vector that dies with this call
+            chk(hipMemcpyAsync(base, hb, up_bytes, hipMemcpyHostToDevice, b->st));
+            chk(hipStreamSynchronize(b->st));   // the copy reads a host vector that dies with this call
         }
     }
     if (e != hipSuccess) {
@@ -1168,7 +1189,7 @@ extern "C" int ns_batch_run(ns_batch* b, int run_flags) {
     ns_ctx* ctx = b->ctx;
     const int timed = run_flags & NS_RUN_TIMED;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
+    hipStream_t st = b->st;
     const bool and_mode = (b->flags & NS_FLAG_AND) != 0;
     hipEvent_t* ev = nullptr;
     if (timed) {
@@ -1307,7 +1328,7 @@ extern "C" int ns_batch_sync(ns_batch* b) {
     if (!b) return NS_E_INVAL;
     ns_ctx* ctx = b->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(b->st));
     return batch_collect_timings(b);
 }
 
@@ -1316,7 +1337,7 @@ extern "C" int ns_batch_fetch(ns_batch* b, ns_hit* hits_out, uint32_t* nhits_out
     ns_ctx* ctx = b->ctx;
     if (!b->ran) return fail(ctx, NS_E_STATE, "ns_batch_fetch before ns_batch_run");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
+    hipStream_t st = b->st;
     const bool own_outputs = b->o_hits == b->d_hits && b->o_nhits == b->d_nhits && b->o_found == b->d_found;
     if (b->done_recorded && own_outputs) {   // NS_RUN_FETCH: wait for this batch alone; its results are in (or on their way to) pinned host memory
         HIPCHK(ctx, hipEventSynchronize(b->done));

@@ -260,13 +260,14 @@ def test_overlapping_batches_and_host_thread_count(index_factory):
             assert usable.all()
             descs.append((qd, refs))
         want = [ora.search_batch(qs, 10, threads=16) for qs in sets]
-        for threads in (1, 0, 5):
+        for threads, overlap in ((1, 0), (0, 0), (5, 1), (0, 1)):
             assert L.ns_ctx_set_host_threads(eng.ctx, threads) == 0
+            assert L.ns_ctx_set_overlap(eng.ctx, overlap) == 0   # batches alternate between two streams: tails and heads overlap
             got = list(nsbind.pipelined_search(eng.ctx, descs, 10, timed=True))
             assert len(got) == len(sets)
             for qs, (hits, nhits, found, inf), w in zip(sets, got, want):
                 assert inf.timed_runs == 1 and inf.n_queries == len(qs)
-                assert_same((hits, nhits, found, np.ones(len(qs), np.uint8)), w, qs, f"pipelined, host threads {threads}")
+                assert_same((hits, nhits, found, np.ones(len(qs), np.uint8)), w, qs, f"pipelined, host threads {threads}, overlap {overlap}")
         # the same through preallocated, reused output buffers (what bench.py does)
         k = 10
         out = [(np.empty((4400, k), dtype=nsbind.HIT_DTYPE), np.empty(4400, np.uint32), np.empty(4400, np.uint64)) for _ in range(2)]
@@ -274,6 +275,7 @@ def test_overlapping_batches_and_host_thread_count(index_factory):
             Q = len(sets[i])
             assert_same((hits[:Q].copy(), nhits[:Q].copy(), found[:Q].copy(), np.ones(Q, np.uint8)), want[i], sets[i], "pipelined, reused buffers")
         L.ns_ctx_set_host_threads(eng.ctx, 0)
+        L.ns_ctx_set_overlap(eng.ctx, 0)
     finally:
         eng.close()
         ora.close()
