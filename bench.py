@@ -1,18 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py — queries/sec of the MI355X BM25 hot path + fraction of the HBM roofline.
+"""bench.py — queries/sec of the MI355X BM25 hot path, timed at the C-ABI boundary, + fraction of the HBM roofline.
 
-A "step" is one pass of the hot path (k_bounds -> k_score -> [k_merge]) over one batch of synthetic
-queries whose descriptors and index are already resident in HBM, plus — for N > 1 — the one RCCL
-all-gather of the fixed-size result blocks.  Default workload = BASELINE config 5's query law
-(Zipf-skewed 1-8 term mix, K=10, OR) over the 1M-doc synthetic CORD-19-shaped index, 16384 queries
-per GPU (weak scaling: every rank scores its own 16384-query batch against a replicated index).
+A "step" is one pass of the hot path over one batch of synthetic queries: the batch's term refs sit in HOST memory in
+the C-ABI's layout (what the host facade hands down: lexicon probes and idf done), the index is resident in HBM, and
+the step runs ns_batch_prepare (regroup, cut into work items, upload of the descriptors) -> scoring + merge kernels ->
+results back in host memory (N = 1), resp. -> ONE RCCL all-gather of the packed result blocks (N > 1).  Steps are
+pipelined on the one ctx (prepare(i+1) || run(i) || fetch(i-1), include/nextsearch_hip.h: NS_RUN_FETCH,
+ns_ctx_set_overlap), as a serving loop would run them.  SURVEY.md §8(d): "QPS = batch wall time at the C-ABI boundary,
+H2D of descriptors and D2H of results included, segment upload excluded".
 
-    python bench.py [--gpus N --steps K --warmup W] [--config cfg5|cfg3|cfg4|cfg2] [--variant V]
+Default workload = BASELINE config 5: Zipf-skewed 1-8 term mix, K = 10, OR, 1M-doc synthetic CORD-19-shaped index,
+ONE global batch of 16384 queries.  N > 1: the index is replicated and the batch is cut into N contiguous shards of
+ceil(16384 / N) queries (strong scaling, the way BASELINE configs 4 and 5 are written); `--scaling weak` gives every
+rank a full 16384-query batch of its own instead.
+
+    python bench.py [--gpus N --steps K --warmup W] [--config cfg5|cfg3|cfg4|cfg2] [--scaling strong|weak]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (scoring kernel:
-algorithmic bytes per launch / HIP-event duration, vs 8 TB/s) and, at N=1, `cpu_baseline`
-(the REAL reference engine, oracle/_ref/ref_driver, timed on this box's host on a bounded sample).
+Rank 0 prints ONE JSON line.  Beside the contract's keys it carries
+  roofline       the scoring kernel alone, descriptors resident: algorithmic bytes per launch / HIP-event duration vs 8 TB/s
+  kernel_only    the device-only rate of the same batch (what round 1 reported as `value`)
+  hbm_resident   (N = 1) the same query law over a 20 x 1M-doc index — 1.1 GB of postings, beyond the 256 MiB Infinity
+                 Cache — with its own roofline numbers
+  cpu_baseline   (N = 1) the REAL reference engine on one host core of this box (+ cpu_baselines: the as-shipped
+                 no-flag build, and the oracle port on all cores as the generous upper bound)
 """
 import argparse
 import json
@@ -21,12 +32,20 @@ import subprocess
 import sys
 import tempfile
 import time
+from collections import deque
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, "nextsearch-api_amd")
 sys.path.insert(0, PKG)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what streaming kernels reach
+
+WORKLOAD_TEXT = {
+    "cfg5": "BASELINE config 5 query law: 1-8 terms (1+Poisson(2)), 30% hot ranks [1,32] / 70% log-uniform tail, OR, k=10",
+    "cfg3": "BASELINE config 3: 5-term disjunctive, rank~1/r on [1,5000], k=100",
+    "cfg4": "BASELINE config 4: cfg3 law over 8 x 125k-doc segments, k=10",
+    "cfg2": "BASELINE config 2: 2-term conjunctive (AND extension), ranks U[10,1000], k=10, 100k docs",
+}
 
 
 def parse_args():
@@ -35,42 +54,78 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="cfg5", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
-    ap.add_argument("--queries", type=int, default=0, help="queries per GPU (0 = the config's batch)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = ONE global batch cut into N contiguous shards (default, as BASELINE's configs are written); weak = a full batch per rank")
+    ap.add_argument("--queries", type=int, default=0, help="queries in the global batch (0 = the config's batch)")
+    ap.add_argument("--depth", type=int, default=3, help="batches in flight per ctx in the pipelined loop")
+    ap.add_argument("--no-overlap", action="store_true", help="keep every batch on one stream (default: batches alternate between two)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--min-items", type=int, default=0)
-    ap.add_argument("--split", type=int, default=0, help="postings per work item (0 = library default)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--split", type=int, default=0, help="work units per work item (0 = library default)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the reference CPU baseline sample (0 = skip all CPU baselines)")
     ap.add_argument("--index-dir", default="", help="reuse/generate the index here instead of a temp dir")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL over xGMI; the measured configuration) or gloo (rehearsal of the N > 1 code path with several ranks on ONE GPU)")
-    ap.add_argument("--no-impact-leg", action="store_true", help="skip the extra measurement over the optional impact streams (profiling runs)")
+    ap.add_argument("--no-impact-leg", action="store_true", help="skip the extra measurement over the optional impact streams")
+    ap.add_argument("--no-hbm-leg", action="store_true", help="skip the extra measurement over the 20-segment (HBM-resident) index")
+    ap.add_argument("--hbm-segments", type=int, default=20)
+    ap.add_argument("--hbm-queries", type=int, default=2048)
+    ap.add_argument("--kernel-only", action="store_true", help="profiling runs: only the kernel leg (descriptors resident), no pipelined loop, no extra legs")
     return ap.parse_args()
 
 
-def cpu_baseline(index_dir, queries, k, budget_s):
-    """Reference engine (kind=reference) or, if its binary is absent, the oracle port, on ONE host
-    thread — the reference serialises every search behind Engine::mtx (src/api_engine.cpp:372)."""
-    ref = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
-    port = os.path.join(ROOT, "oracle", "bm25_oracle_cli")
+def host_info():
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"nproc": os.cpu_count(), "cpu_model": model}
+
+
+def cpu_baselines(index_dir, queries, k, budget_s):
+    """The CPU side of SURVEY 8(d), on THIS box's host cores, each on a bounded sample of the same workload:
+      reference -O2, 1 core   cord19::Engine::search compiled from the reference's sources (oracle/_ref/ref_driver); one
+                              core because the reference serialises every search behind Engine::mtx (src/api_engine.cpp:372)
+      reference as shipped    the same with no optimisation flag, as its CMakeLists.txt builds it
+      port, all cores         oracle/bm25_oracle.c (dense accumulator array, canonical tie order: faster than the
+                              reference's hash map), one replica per core: the generous CPU upper bound
+    Returns (headline dict, list of all)."""
+    info = host_info()
+    out = []
     with tempfile.TemporaryDirectory(prefix="ns_cpu_") as tmp:
-        qpath = os.path.join(tmp, "q.txt")
-        sample = queries[:4096]
+        qpath, qpath_all = os.path.join(tmp, "q.txt"), os.path.join(tmp, "q_all.txt")
         with open(qpath, "w") as f:
-            f.write("\n".join(sample) + "\n")
-        for kind, exe in (("reference", ref), ("port", port)):
+            f.write("\n".join(queries[:4096]) + "\n")
+        with open(qpath_all, "w") as f:                    # all cores need more work than one core: the whole batch, 8 times over
+            for _ in range(8):
+                f.write("\n".join(queries) + "\n")
+        runs = [
+            ("reference", os.path.join(ROOT, "oracle", "_ref", "ref_driver"), budget_s, 1,
+             "cord19::Engine::search built -O2 from the reference sources, search cache emptied per call"),
+            ("reference", os.path.join(ROOT, "oracle", "_ref", "ref_driver_O0"), min(budget_s, 6.0), 1,
+             "the same engine as shipped: no optimisation flag (the reference's CMakeLists.txt sets none)"),
+            ("port", os.path.join(ROOT, "oracle", "bm25_oracle_cli"), min(budget_s, 5.0), info["nproc"] or 1,
+             "oracle/bm25_oracle.c (dense accumulators, canonical order), queries partitioned over all cores"),
+        ]
+        for kind, exe, secs, threads, what in runs:
             if not os.path.exists(exe):
                 continue
             try:
-                cmd = [exe, "time", index_dir, qpath, str(k), str(budget_s)] + (["1"] if kind == "port" else [])
-                out = subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=budget_s * 4 + 120).stdout
-                r = json.loads(out.strip().splitlines()[-1])
-                return {"value": r["qps"], "unit": "queries/s", "cores": 1, "kind": kind,
-                        "sample": f"first {r['queries']} queries of the same workload, {r['seconds']:.1f} s, "
-                                  + ("cord19::Engine::search built -O2 from the reference sources (search cache emptied per call)"
-                                     if kind == "reference" else "oracle/bm25_oracle.c, 1 thread")}
+                cmd = [exe, "time", index_dir, qpath_all if kind == "port" else qpath, str(k), str(secs)] + ([str(threads)] if kind == "port" else [])
+                res = subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=secs * 6 + 180).stdout
+                r = json.loads(res.strip().splitlines()[-1])
+                out.append({"value": r["qps"], "unit": "queries/s", "cores": threads, "kind": kind, "nproc": info["nproc"], "cpu_model": info["cpu_model"],
+                            "sample": f"{r['queries']} queries of the same workload, {r['seconds']:.1f} s; {what}"})
             except Exception as e:   # noqa: BLE001
                 sys.stderr.write(f"[bench] cpu baseline via {exe} failed: {e}\n")
-    return None
+    if not out:
+        return None, []
+    return out[0], out
 
 
 def main():
@@ -102,12 +157,23 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend="gloo")
+    L = nsbind.hip_lib()
 
     gen, q_default, K, flags, (nseg, docs) = workloads.WORKLOADS[args.config]
-    Q = args.queries or q_default
+    Q = args.queries or q_default                       # the global batch (strong) / the per-rank batch (weak)
     seed = {"cfg2": 2002, "cfg3": 2003, "cfg4": 2004, "cfg5": 2005}[args.config]
-    # weak scaling: each rank owns a full batch of its own (different seed), index replicated
-    queries = gen(Q, seed + 7919 * rank)
+    strong = args.scaling == "strong" or n_gpus == 1
+    if strong:
+        all_queries = gen(Q, seed)                      # ONE global batch, the same on every rank
+        lo, hi = shard.shard_bounds(Q, rank, n_gpus)    # this rank's contiguous shard: ceil(Q / N) queries, the last may be short
+        queries = all_queries[lo:hi]
+        per = (Q + n_gpus - 1) // n_gpus                # rows of every rank's result block (short shards are padded)
+        global_batch = Q
+    else:
+        queries = gen(Q, seed + 7919 * rank)            # a full batch of its own per rank
+        per = Q
+        global_batch = n_gpus * Q
+    Qr = len(queries)
 
     tmp = None
     if args.index_dir:
@@ -123,152 +189,243 @@ def main():
 
     os.environ["NS_RELOAD_WARMUP"] = "0"   # no warm-up query at reload: rocprof / PMC summaries of this command then hold the batch launches only
     eng = nsbind.Engine(index_dir, local_rank)
-    stream = torch.cuda.current_stream()
-    nsbind.hip_lib().ns_ctx_set_stream(eng.ctx, stream.cuda_stream)
     eng.set_tuning(args.variant, args.min_items, args.split)
+    # the step's INPUT: the shard's term refs in host memory, in the C-ABI's layout (tokenise + lexicon probes + idf done)
+    qd, refs, usable = eng.build_refs(queries)
+    assert usable.all()
 
-    batch = eng.prepare(queries, K, flags)
-    l_hits = torch.zeros((Q, K, 3), dtype=torch.int32, device="cuda")
-    l_nhits = torch.zeros(Q, dtype=torch.int32, device="cuda")
-    l_found = torch.zeros(Q, dtype=torch.int64, device="cuda")
-    batch.bind_outputs(l_hits.data_ptr(), l_nhits.data_ptr(), l_found.data_ptr())
-    gathered = None
-    if dist is not None:
-        gathered = (torch.empty((n_gpus * Q, K, 3), dtype=torch.int32, device="cuda"),
-                    torch.empty(n_gpus * Q, dtype=torch.int32, device="cuda"),
-                    torch.empty(n_gpus * Q, dtype=torch.int64, device="cuda"))
-
-    # setup, before the contract's W warm-up steps: the first launches after an idle period run ~10 % slow while the
-    # device clocks ramp (3.17, 3.12, 3.04, 2.97, 2.90, then 2.83 ms in profiles/r01/final_cfg5_kernel_trace_head.csv)
+    # ---- kernel leg: descriptors resident in HBM, the scoring launch alone under HIP events (the roofline's numbers) ----
+    kb = nsbind.prepare_raw(eng.ctx, qd, refs, K, flags)
+    # the first launches after an idle period run ~10 % slow while the device clocks ramp (profiles/r01/final_cfg5_kernel_trace_head.csv)
     for _ in range(6):
-        batch.run(timed=False)
-    torch.cuda.synchronize()
-
-    def step(timed):
-        batch.run(timed=timed)
-        if dist is not None:
-            shard.gather_results(l_hits, l_nhits, l_found, out=gathered)
-
+        kb.run(timed=False)
+    kb.sync()
     for _ in range(args.warmup):
-        step(False)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+        kb.run(timed=False)
+    kb.sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(True)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    batch.sync()   # reads the HIP events recorded on the stream during the timed region
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        kb.run(timed=True)
+    kb.sync()   # also reads the HIP events recorded on the stream
+    kernel_elapsed = time.perf_counter() - t0
+    kinfo = kb.info()
+    k_hits, k_nhits, k_found = kb.fetch()
+    assert (k_nhits == np.minimum(k_found, K)).all(), "result sanity check failed"
+    kb.close()
+    score_ms = kinfo.sum_score_kernel_ms / max(kinfo.timed_runs, 1)
+    total_ms = kinfo.sum_total_ms / max(kinfo.timed_runs, 1)
 
-    info = batch.info()
-    # sanity: results of the timed region are real
-    nh = l_nhits.cpu().numpy()
-    fd = l_found.cpu().numpy()
-    assert (nh == np.minimum(fd, K)).all(), "result sanity check failed"
+    # ---- value leg: K pipelined steps at the C-ABI boundary ----
+    elapsed = None
+    if not args.kernel_only:
+        L.ns_ctx_set_overlap(eng.ctx, 0 if args.no_overlap else 1)
+        depth = max(1, args.depth)
+        if dist is None:
+            out = [(np.empty((Qr, K), dtype=nsbind.HIT_DTYPE), np.empty(Qr, np.uint32), np.empty(Qr, np.uint64)) for _ in range(2)]
 
-    # Extra leg (N=1, reported next to the headline, never as `value`): the same batch over the optional
-    # impact streams ({docId, precomputed term score}; ns_segment_build_impacts).  Same K steps, same
-    # timing; the result tensors must equal the headline run's byte for byte.
+            def run_steps(n):
+                last = None
+                for res in nsbind.pipelined_search(eng.ctx, [(qd, refs)] * n, K, flags, out=out, depth=depth):
+                    last = res
+                return last
+
+            run_steps(args.warmup)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            last = run_steps(args.steps)
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+            # the timed region's results are real: the last step's host buffers equal the kernel leg's
+            assert last[0].tobytes() == k_hits.tobytes() and last[1].tobytes() == k_nhits.tobytes() and last[2].tobytes() == k_found.tobytes(), \
+                "pipelined results differ from the kernel leg's"
+        else:
+            # every rank: prepare(own shard) -> kernels into ITS packed block -> ONE all-gather of the blocks (asynchronous,
+            # ordered behind the batch's stream); up to `depth` steps in flight
+            nbytes, off_n, off_f = shard.packed_layout(per, K)
+            blocks = [shard.alloc_packed(per, K, "cuda") for _ in range(depth)]
+            gathered = [torch.empty(n_gpus * nbytes, dtype=torch.uint8, device="cuda") for _ in range(depth)]
+            torch.cuda.synchronize()
+
+            def run_steps(n):
+                flight = deque()
+                for i in range(n):
+                    if len(flight) >= depth:
+                        flight.popleft()()
+                    b = nsbind.prepare_raw(eng.ctx, qd, refs, K, flags)
+                    blk = blocks[i % depth]
+                    b.bind_outputs(blk.data_ptr(), blk.data_ptr() + off_n, blk.data_ptr() + off_f)
+                    b.run(timed=False)
+                    st = torch.cuda.ExternalStream(b.stream)
+                    with torch.cuda.stream(st):
+                        work = shard.gather_packed(blk, gathered[i % depth], async_op=True)
+                        work.wait()                      # the batch's stream waits for the collective (no host block)
+                        ev = torch.cuda.Event()
+                        ev.record(st)
+
+                    def retire(b=b, ev=ev):
+                        ev.synchronize()
+                        b.close()
+                    flight.append(retire)
+                while flight:
+                    flight.popleft()()
+
+            run_steps(args.warmup)
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_steps(args.steps)
+            torch.cuda.synchronize()
+            dist.barrier()
+            elapsed = time.perf_counter() - t0
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            # sanity: the gathered blocks hold this rank's own kernel-leg results at its place
+            gh, gn, gf = shard.packed_views(gathered[(args.steps - 1) % depth], per, K, n_gpus)
+            assert np.array_equal(gn[rank, :Qr].cpu().numpy().astype(np.uint32), k_nhits) and np.array_equal(gf[rank, :Qr].cpu().numpy().astype(np.uint64), k_found), \
+                "gathered results differ from the kernel leg's"
+        L.ns_ctx_set_overlap(eng.ctx, 0)
+
+    # ---- extra legs (N = 1 only; reported next to the headline, never as `value`) ----
     impact_leg = None
-    if n_gpus == 1 and args.variant == 0 and not args.no_impact_leg:
+    if n_gpus == 1 and args.variant == 0 and not args.no_impact_leg and not args.kernel_only:
         t0 = time.perf_counter()
         eng.build_impacts()
         build_s = time.perf_counter() - t0
-        b2 = eng.prepare(queries, K, flags)
-        i_hits, i_nhits, i_found = torch.zeros_like(l_hits), torch.zeros_like(l_nhits), torch.zeros_like(l_found)
-        b2.bind_outputs(i_hits.data_ptr(), i_nhits.data_ptr(), i_found.data_ptr())
+        b2 = nsbind.prepare_raw(eng.ctx, qd, refs, K, flags)
         for _ in range(args.warmup):
             b2.run(timed=False)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        b2.sync()
         for _ in range(args.steps):
             b2.run(timed=True)
-        torch.cuda.synchronize()
-        el2 = time.perf_counter() - t0
         b2.sync()
         inf2 = b2.info()
-        same = bool(torch.equal(i_hits, l_hits) and torch.equal(i_nhits, l_nhits) and torch.equal(i_found, l_found))
+        i_hits, i_nhits, i_found = b2.fetch()
+        same = i_hits.tobytes() == k_hits.tobytes() and i_nhits.tobytes() == k_nhits.tobytes() and i_found.tobytes() == k_found.tobytes()
         assert inf2.flags & nsbind.NS_INFO_IMPACTS, "the impact leg did not read the impact streams"
         assert same, "impact-stream results differ from the {docId, tf} path"
         k2 = inf2.sum_score_kernel_ms / max(inf2.timed_runs, 1)
         impact_leg = {
-            "what": "same batch, postings read as {docId, precomputed fp32 term score} (optional second stream, built once per list)",
-            "value": Q * args.steps / el2, "unit": "queries/s", "ms_per_step": el2 / args.steps * 1e3,
+            "what": "same batch, kernel only, postings read as {docId, precomputed fp32 term score} (optional second stream, built once per list)",
             "kernel_ms": k2, "achieved": inf2.algo_bytes / (k2 * 1e-3) / 1e9 if k2 > 0 else 0.0,
             "frac": (inf2.algo_bytes / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS) if k2 > 0 else 0.0,
             "build_s": build_s, "identical_results": same,
         }
         b2.close()
+        eng.use_impacts(False)
+
+    traffic_db = {}
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            with open(tpath) as f:
+                traffic_db = json.load(f)
+        except Exception:   # noqa: BLE001
+            traffic_db = {}
+
+    hbm_leg = None
+    if n_gpus == 1 and args.config == "cfg5" and not args.no_hbm_leg and not args.kernel_only:
+        # The same query law over an index that cannot sit in the 256 MiB Infinity Cache: S x 1M docs (every query scans all
+        # S segments: S x the postings per query; 20 segments = 1.1 GB of postings + 0.55 GB of per-posting norms).
+        S, Qb = args.hbm_segments, args.hbm_queries
+        with tempfile.TemporaryDirectory(prefix="ns_bench_big_") as big:
+            bidx = os.path.join(big, "index")
+            nsbind.gen_index(bidx, S, docs, 65536, 1337, False)
+            beng = nsbind.Engine(bidx, local_rank)
+            beng.set_tuning(args.variant, args.min_items, args.split)
+            bq = gen(Qb, seed)
+            bqd, brefs, _ = beng.build_refs(bq)
+            bb = nsbind.prepare_raw(beng.ctx, bqd, brefs, K, flags)
+            for _ in range(3):
+                bb.run(timed=False)
+            bb.sync()
+            n_big = max(5, args.steps // 2)
+            for _ in range(n_big):
+                bb.run(timed=True)
+            bb.sync()
+            binf = bb.info()
+            bh, bn, bf = bb.fetch()
+            assert (bn == np.minimum(bf, K)).all()
+            bb.close()
+            bms = binf.sum_score_kernel_ms / max(binf.timed_runs, 1)
+            bach = binf.algo_bytes / (bms * 1e-3) / 1e9
+            dev_bytes = sum(beng.segment_info(s)["n_postings"] for s in range(S)) * 12
+            tr = traffic_db.get(f"cfg5_big{S}_q{Qb}")
+            hbm_leg = {
+                "what": f"cfg5 query law, {Qb} queries over {S} segments x {docs} docs (every query scans every segment), kernel only",
+                "index_bytes_on_device": int(dev_bytes), "postings_per_query": binf.postings / max(Qb, 1), "work_items": binf.n_items,
+                "kernel_ms": bms, "queries_per_s_kernel": Qb / (bms * 1e-3),
+                "roofline": {"bound": "hbm", "achieved": bach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bach / HBM_PEAK_GBS,
+                             "algo_bytes_per_launch": int(binf.algo_bytes), "traffic": tr,
+                             "traffic_source": "L2-miss bytes per launch from the builder's rocprofv3 --pmc FETCH_SIZE pass of this leg (x2 gfx950 correction), profiles/r02; not measured in this run",
+                             "limited_by": "memory: the launch moves ~2x its algorithmic bytes (12 B per posting by design + re-read partial rounds) at ~6 TB/s of L2-miss traffic, the rate streaming kernels reach on this part (~6.3 TB/s)"},
+            }
+            beng.close()
 
     if rank == 0:
-        score_ms = info.sum_score_kernel_ms / max(info.timed_runs, 1)
-        total_ms = info.sum_total_ms / max(info.timed_runs, 1)
-        achieved = info.algo_bytes / (score_ms * 1e-3) / 1e9 if score_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                with open(tpath) as f:
-                    tj = json.load(f)
-                traffic = tj.get(f"{args.config}_v{args.variant}_q{Q}")
-            except Exception:   # noqa: BLE001
-                traffic = None
+        achieved = kinfo.algo_bytes / (score_ms * 1e-3) / 1e9 if score_ms > 0 else 0.0
+        traffic = traffic_db.get(f"{args.config}_v{args.variant}_q{Qr}")
+        value = (global_batch * args.steps / elapsed) if elapsed else (Qr * n_gpus * args.steps / kernel_elapsed)
         line = {
             "metric": "queries/sec at k=10 over 1M-doc index; achieved HBM GB/s vs peak" if args.config in ("cfg5", "cfg4")
                       else f"queries/sec ({args.config})",
-            "value": n_gpus * Q * args.steps / elapsed,
+            "value": value,
             "unit": "queries/s",
             "n_gpus": n_gpus,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": (elapsed if elapsed else kernel_elapsed) / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": {"cfg5": "BASELINE config 5 query law: 1-8 terms (1+Poisson(2)), 30% hot ranks [1,32] / 70% log-uniform tail, OR, k=10",
-                             "cfg3": "BASELINE config 3: 5-term disjunctive, rank~1/r on [1,5000], k=100",
-                             "cfg4": "BASELINE config 4: cfg3 law over 8 x 125k-doc segments, k=10",
-                             "cfg2": "BASELINE config 2: 2-term conjunctive (AND extension), ranks U[10,1000], k=10, 100k docs"}[args.config],
-                "index": f"{nseg} segment(s) x {docs} docs, 65536-term Zipf vocabulary, {info.postings / max(Q,1):.0f} postings/query",
-                "queries_per_gpu": Q,
-                "global_batch": n_gpus * Q,
+                "workload": WORKLOAD_TEXT[args.config],
+                "index": f"{nseg} segment(s) x {docs} docs, 65536-term Zipf vocabulary, {kinfo.postings / max(Qr, 1):.0f} postings/query",
+                "global_batch": global_batch,
+                "queries_per_gpu": Qr,
                 "k": K,
-                "parallelism": f"query-sharded x{n_gpus}, index replicated" + (", RCCL all-gather of results per step" if n_gpus > 1 else ""),
+                "parallelism": (f"query-sharded x{n_gpus}: index replicated, " + ("one global batch in contiguous shards" if strong else "a full batch per rank")
+                                + (", ONE RCCL all-gather of the packed result blocks per step" if n_gpus > 1 else "")),
+                "timed_region": ("per step: ns_batch_prepare from host-resident term refs (regroup, work items, H2D) -> scoring + merge kernels -> "
+                                 + ("results in host memory" if n_gpus == 1 else "all-gather of all ranks' results on the device")
+                                 + f"; {args.depth} steps in flight per ctx" + ("" if args.no_overlap else ", alternating between two streams")) if elapsed else "kernel leg only (--kernel-only)",
                 "kernel_variant": args.variant,
-                "work_items": info.n_items,
+                "work_items": kinfo.n_items,
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_uscore" if args.variant == 0 else "k_dscore" if args.variant in (12, 13, 14, 15, 16, 17) else "k_tscore" if args.variant in (18, 19, 20) else ("k_wscore" if args.variant in (5, 6, 7, 8, 9, 10, 11) else "k_score"),
+                "kernel": "k_uscore" if args.variant == 0 else "k_dscore" if args.variant in (12, 13, 14, 15, 16, 17) else "k_tscore" if args.variant in (18, 19, 20) else "k_score",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "algo_bytes_per_launch": int(info.algo_bytes),
+                "traffic_source": "L2-miss bytes per launch from the builder's rocprofv3 --pmc FETCH_SIZE pass of this command (x2 gfx950 correction), profiles/; not measured in this run",
+                "limited_by": ("instruction issue: this index (83 MB on the device) is Infinity-Cache resident, single hot lists stream at > 8 TB/s of algorithmic bytes, "
+                               "and the SIMDs' vector and scalar issue slots are 70-77 % busy (profiles/: SQ_INSTS_VALU / SQ_INSTS_SALU vs SQ_BUSY_CYCLES); see hbm_resident for the memory-bound leg")
+                              if args.config in ("cfg5", "cfg3", "cfg4") else "launch latency (a few tens of microseconds of work)",
+                "algo_bytes_per_launch": int(kinfo.algo_bytes),
                 "kernel_ms": score_ms,
                 "all_kernels_ms": total_ms,
+                "measured": "HIP events on the ctx stream around every scoring launch of the kernel leg (descriptors resident, one batch at a time)",
             },
+            "kernel_only": {"value": Qr * n_gpus * args.steps / kernel_elapsed, "unit": "queries/s", "ms_per_step": kernel_elapsed / args.steps * 1e3,
+                            "what": "device-only: the prepared batch re-run with descriptors resident in HBM (round 1's `value`)"},
+            "host": host_info(),
         }
-        if n_gpus == 1 and args.cpu_seconds > 0 and flags == 0:
-            cb = cpu_baseline(index_dir, queries, K, args.cpu_seconds)
+        if n_gpus == 1 and args.cpu_seconds > 0 and flags == 0 and not args.kernel_only:
+            cb, allcb = cpu_baselines(index_dir, queries, K, args.cpu_seconds)
             if cb is not None:
                 line["cpu_baseline"] = cb
+                line["cpu_baselines"] = allcb
+        if hbm_leg is not None:
+            line["hbm_resident"] = hbm_leg
         if impact_leg is not None:
             line["impact_stream"] = impact_leg
         print(json.dumps(line), flush=True)
 
-    batch.close()
     eng.close()
     if dist is not None:
         dist.barrier()

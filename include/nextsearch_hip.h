@@ -169,6 +169,9 @@ int  ns_batch_bind_outputs(ns_batch* b, void* d_hits, void* d_nhits, void* d_fou
 #define NS_RUN_TIMED 1
 #define NS_RUN_FETCH 2
 int  ns_batch_run(ns_batch* b, int run_flags);
+/* The hipStream_t this batch's work is enqueued on (the ctx's stream, or its second one under ns_ctx_set_overlap) —
+ * for callers that order their own device work behind the batch (bench.py: the RCCL all-gather of a rank's results). */
+void* ns_batch_stream(ns_batch* b);
 int  ns_batch_sync(ns_batch* b);
 int  ns_batch_fetch(ns_batch* b, ns_hit* hits_out, uint32_t* nhits_out, uint64_t* found_out);
 int  ns_batch_get_info(ns_batch* b, ns_batch_info* info);

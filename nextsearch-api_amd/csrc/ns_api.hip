@@ -624,6 +624,7 @@ struct ns_batch {
     hipStream_t st = nullptr;  // the stream all of this batch's work goes to (the ctx's, or its second one when overlap is on)
     hipEvent_t done = nullptr;
     bool done_recorded = false;
+    bool fetch_enqueued = false;   // the last run carried NS_RUN_FETCH
     int down_slot = -1;        // index into ns_ctx::down_slots while a D2H copy is pending or unread
 };
 
@@ -1303,12 +1304,17 @@ extern "C" int ns_batch_run(ns_batch* b, int run_flags) {
             }
             HIPCHK(ctx, hipMemcpyAsync(ctx->down_slots[(size_t)b->down_slot].p, b->d_hits, b->out_span, hipMemcpyDeviceToHost, st));
         }
-        if (!b->done) HIPCHK(ctx, hipEventCreateWithFlags(&b->done, hipEventDisableTiming));
-        HIPCHK(ctx, hipEventRecord(b->done, st));
-        b->done_recorded = true;
     }
+    // completion event of THIS run: destroy (and a NS_RUN_FETCH fetch) wait for it instead of for the whole stream
+    if (!b->done) HIPCHK(ctx, hipEventCreateWithFlags(&b->done, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventRecord(b->done, st));
+    b->done_recorded = true;
+    b->fetch_enqueued = (run_flags & NS_RUN_FETCH) != 0;
     return NS_OK;
 }
+
+extern "C" void* ns_batch_stream(ns_batch* b) { return b ? (void*)b->st : nullptr; }
+
 
 // reads the HIP-event timings of the runs since the last call (all of them lie before the point the caller has waited for)
 static int batch_collect_timings(ns_batch* b) {
@@ -1339,7 +1345,7 @@ extern "C" int ns_batch_fetch(ns_batch* b, ns_hit* hits_out, uint32_t* nhits_out
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = b->st;
     const bool own_outputs = b->o_hits == b->d_hits && b->o_nhits == b->d_nhits && b->o_found == b->d_found;
-    if (b->done_recorded && own_outputs) {   // NS_RUN_FETCH: wait for this batch alone; its results are in (or on their way to) pinned host memory
+    if (b->fetch_enqueued && b->done_recorded && own_outputs) {   // NS_RUN_FETCH: wait for this batch alone; its results are in (or on their way to) pinned host memory
         HIPCHK(ctx, hipEventSynchronize(b->done));
         int rc = batch_collect_timings(b);
         if (rc != NS_OK) return rc;

@@ -15,7 +15,11 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
+#include <exception>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -117,10 +121,12 @@ inline GenStats generate_index(const GenParams& p) {
     fs::path root(p.index_dir);
     fs::create_directories(root / "segments");
     std::vector<std::string> names;
-    TfSampler tfs;
-    for (uint32_t seg = 0; seg < p.n_segments; seg++) {
-        std::string name = seg_name(seg + 1);
-        names.push_back(name);
+    for (uint32_t seg = 0; seg < p.n_segments; seg++) names.push_back(seg_name(seg + 1));
+    const TfSampler tfs;
+    std::vector<uint64_t> seg_postings(p.n_segments, 0);
+    // segments are independent (every draw is seeded by (seed, segment, rank)): several at a time, same bytes
+    auto make_segment = [&](uint32_t seg) {
+        const std::string& name = names[seg];
         fs::path d = root / "segments" / name;
         fs::create_directories(d);
         const uint32_t N = p.docs_per_segment;
@@ -180,7 +186,7 @@ inline GenStats generate_index(const GenParams& p) {
                         inv.raw(pairs.data(), pairs.size() * 4);
                         off += (uint64_t)df * 8;
                         nrec++;
-                        st.total_postings += df;
+                        seg_postings[seg] += df;
                     }
                     tid++;
                 }
@@ -204,11 +210,31 @@ inline GenStats generate_index(const GenParams& p) {
                 inv.raw(pairs.data(), pairs.size() * 4);
                 off += (uint64_t)df * 8;
                 nrec++;
-                st.total_postings += df;
+                seg_postings[seg] += df;
             }
             lex.patch_u32_at0(nrec);
         }
+    };
+    {
+        const unsigned nt = std::max(1u, std::min<unsigned>({p.n_segments, std::thread::hardware_concurrency(), 16u}));
+        if (nt <= 1) {
+            for (uint32_t seg = 0; seg < p.n_segments; seg++) make_segment(seg);
+        } else {
+            std::atomic<uint32_t> next{0};
+            std::exception_ptr err;
+            std::mutex err_m;
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; t++)
+                th.emplace_back([&]() {
+                    try {
+                        for (uint32_t seg = next++; seg < p.n_segments; seg = next++) make_segment(seg);
+                    } catch (...) { std::lock_guard<std::mutex> l(err_m); if (!err) err = std::current_exception(); }
+                });
+            for (auto& t : th) t.join();
+            if (err) std::rethrow_exception(err);
+        }
     }
+    for (uint64_t n : seg_postings) st.total_postings += n;
     save_manifest(root / "manifest.bin", names);
     st.total_bytes = st.total_postings * 8;
     return st;

@@ -53,7 +53,7 @@ assert QDESC_DTYPE.itemsize == C.sizeof(NsQueryDesc) == 8
 HIP_SYMBOLS = [
     "ns_ctx_create", "ns_ctx_destroy", "ns_ctx_set_stream", "ns_last_error", "ns_device_name",
     "ns_segment_upload", "ns_segment_release", "ns_segment_upload_begin", "ns_segment_upload_append", "ns_segment_upload_end", "ns_search_batch", "ns_batch_prepare",
-    "ns_batch_bind_outputs", "ns_batch_run", "ns_batch_sync", "ns_batch_fetch", "ns_batch_get_info",
+    "ns_batch_bind_outputs", "ns_batch_run", "ns_batch_stream", "ns_batch_sync", "ns_batch_fetch", "ns_batch_get_info",
     "ns_batch_destroy", "ns_set_tuning", "ns_segment_build_impacts", "ns_ctx_use_impacts", "ns_ctx_set_host_threads", "ns_ctx_set_overlap",
     "ns_invert_forward", "ns_merge_rank_rows", "ns_sem_upload", "ns_sem_release", "ns_sem_topk",
 ]
@@ -105,6 +105,8 @@ def hip_lib():
         L.ns_batch_prepare.argtypes = [vp, vp, vp, u32, u32, u32, C.POINTER(vp)]
         L.ns_batch_bind_outputs.argtypes = [vp, vp, vp, vp]
         L.ns_batch_run.argtypes = [vp, i32]
+        L.ns_batch_stream.argtypes = [vp]
+        L.ns_batch_stream.restype = vp
         L.ns_batch_sync.argtypes = [vp]
         L.ns_batch_fetch.argtypes = [vp, vp, vp, vp]
         L.ns_batch_get_info.argtypes = [vp, C.POINTER(NsBatchInfo)]
@@ -210,6 +212,11 @@ class Batch:
         rc = hip_lib().ns_batch_run(self.h, int(bool(timed)) | (2 if fetch else 0))
         if rc != NS_OK:
             raise RuntimeError(f"ns_batch_run failed rc={rc}")
+
+    @property
+    def stream(self):
+        """hipStream_t (integer) the batch's work goes to."""
+        return hip_lib().ns_batch_stream(self.h)
 
     def sync(self):
         rc = hip_lib().ns_batch_sync(self.h)
@@ -454,34 +461,30 @@ def prepare_raw(ctx, qd, refs, k, flags=NS_FLAG_OR):
     return Batch(b, len(qd), int(k))
 
 
-def pipelined_search(ctx, batches, k, flags=NS_FLAG_OR, out=None, timed=False):
-    """Host -> host search of a sequence of batches [(qd, refs), ...] with two batches in flight on the one ctx:
-    while the device scores batch i the host prepares and uploads batch i+1, and batch i's results are fetched as
-    soon as they have landed (NS_RUN_FETCH).  Yields (hits, nhits, found, info) per batch, in order.  `out`: optional
-    list of preallocated (hits, nhits, found) triples, reused round-robin (at least 2)."""
-    def bufs(i, Q):
-        if out is not None:
-            return out[i % len(out)]
-        return (np.empty((Q, k), dtype=HIT_DTYPE), np.empty(Q, dtype=np.uint32), np.empty(Q, dtype=np.uint64))
-    prev = None
-    for i, (qd, refs) in enumerate(batches):
-        b = prepare_raw(ctx, qd, refs, k, flags)
-        b.run(timed=timed, fetch=True)
-        if prev is not None:
-            pb, pi = prev
-            o = bufs(pi, pb.Q)
-            pb.fetch_into(*o)
-            inf = pb.info()
-            pb.close()
-            yield o + (inf,)
-        prev = (b, i)
-    if prev is not None:
-        pb, pi = prev
-        o = bufs(pi, pb.Q)
+def pipelined_search(ctx, batches, k, flags=NS_FLAG_OR, out=None, timed=False, depth=2):
+    """Host -> host search of a sequence of batches [(qd, refs), ...] with up to `depth` batches in flight on the one
+    ctx: while the device scores batch i the host prepares and uploads batch i+1 (.. i+depth-1), and batch i's results
+    are fetched as soon as they have landed (NS_RUN_FETCH).  Yields (hits, nhits, found, info) per batch, in order.
+    `out`: optional list of preallocated (hits, nhits, found) triples, reused round-robin (any number >= 1: a triple
+    is only written when its batch is fetched)."""
+    from collections import deque
+
+    def collect(pb, pi):
+        o = out[pi % len(out)] if out is not None else (np.empty((pb.Q, k), dtype=HIT_DTYPE), np.empty(pb.Q, dtype=np.uint32), np.empty(pb.Q, dtype=np.uint64))
         pb.fetch_into(*o)
         inf = pb.info()
         pb.close()
-        yield o + (inf,)
+        return o + (inf,)
+
+    flight = deque()
+    for i, (qd, refs) in enumerate(batches):
+        b = prepare_raw(ctx, qd, refs, k, flags)
+        b.run(timed=timed, fetch=True)
+        flight.append((b, i))
+        if len(flight) >= depth:
+            yield collect(*flight.popleft())
+    while flight:
+        yield collect(*flight.popleft())
 
 
 def search_batch_raw(ctx, qd, refs, k, flags=NS_FLAG_OR):

@@ -1,7 +1,7 @@
 """Query-parallel multi-GPU plumbing: the index is replicated on every GPU, each
 rank scores its own contiguous shard of the query batch, and the fixed-size result blocks are
-gathered with ONE collective per batch (RCCL all-gather over xGMI when the backend is "nccl";
-gloo on CPU in the tests).  No collective touches the posting data path."""
+gathered with ONE collective per batch — hits, nhits and found travel as one packed block (RCCL all-gather over xGMI
+when the backend is "nccl"; gloo on CPU in the tests).  No collective touches the posting data path."""
 import torch
 import torch.distributed as dist
 
@@ -13,18 +13,67 @@ def shard_bounds(n, rank, world):
     return lo, min(n, lo + per)
 
 
+def _align(n, a=256):
+    return (n + a - 1) // a * a
+
+
+def packed_layout(rows, k):
+    """One result block = [hits rows*k*12 B | nhits rows*4 B | found rows*8 B], sections 256-byte aligned, so that a
+    rank's whole answer is ONE buffer and the step's exchange ONE collective.  -> (nbytes, off_nhits, off_found)."""
+    off_n = _align(rows * k * 12)
+    off_f = off_n + _align(rows * 4)
+    return off_f + _align(rows * 8), off_n, off_f
+
+
+def alloc_packed(rows, k, device, world=1):
+    nbytes, _, _ = packed_layout(rows, k)
+    return torch.zeros(world * nbytes, dtype=torch.uint8, device=device)
+
+
+def packed_views(buf, rows, k, world=1):
+    """Typed views of `world` result blocks laid out back to back in `buf` (uint8): hits [W, rows, k, 3] int32
+    (score bits, seg, doc), nhits [W, rows] int32, found [W, rows] int64.  No copies."""
+    nbytes, off_n, off_f = packed_layout(rows, k)
+    blocks = buf.view(world, nbytes)
+    hits = blocks[:, : rows * k * 12].view(torch.int32).view(world, rows, k, 3)
+    nhits = blocks[:, off_n: off_n + rows * 4].view(torch.int32).view(world, rows)
+    found = blocks[:, off_f: off_f + rows * 8].view(torch.int64).view(world, rows)
+    return hits, nhits, found
+
+
+def gather_packed(block, out, group=None, async_op=False):
+    """THE exchange step of the query-sharded path: every rank contributes its packed result block (equal size on all
+    ranks: short last shards are padded to ceil(Q / world) rows), every rank receives all of them, rank-major."""
+    return dist.all_gather_into_tensor(out, block, group=group, async_op=async_op)
+
+
+def unshard(gathered, n_queries, world, k):
+    """The global batch's results from the gathered blocks: drops the padding rows of short shards.
+    -> hits [Q, k, 3] int32, nhits [Q] int32, found [Q] int64 (copies)."""
+    per = (n_queries + world - 1) // world
+    hits, nhits, found = packed_views(gathered, per, k, world)
+    keep = [min(per, max(0, n_queries - r * per)) for r in range(world)]
+    return (torch.cat([hits[r, : keep[r]] for r in range(world)]), torch.cat([nhits[r, : keep[r]] for r in range(world)]),
+            torch.cat([found[r, : keep[r]] for r in range(world)]))
+
+
 def gather_results(hits, nhits, found, out=None, group=None):
-    """All-gather per-rank result blocks of EQUAL shape: hits [Q,K,3] int32 (score bits, seg, doc),
-    nhits [Q] int32, found [Q] int64 -> ([W*Q,K,3], [W*Q], [W*Q]) on every rank, rank-major."""
+    """All-gather per-rank result arrays of EQUAL shape: hits [Q,K,3] int32 (score bits, seg, doc), nhits [Q] int32,
+    found [Q] int64 -> ([W*Q,K,3], [W*Q], [W*Q]) on every rank, rank-major.  The three arrays travel as ONE packed
+    block in ONE collective (packed_layout)."""
     world = dist.get_world_size(group)
-    if out is None:
-        out = (torch.empty((world * hits.shape[0],) + tuple(hits.shape[1:]), dtype=hits.dtype, device=hits.device),
-               torch.empty(world * nhits.shape[0], dtype=nhits.dtype, device=nhits.device),
-               torch.empty(world * found.shape[0], dtype=found.dtype, device=found.device))
-    dist.all_gather_into_tensor(out[0], hits, group=group)
-    dist.all_gather_into_tensor(out[1], nhits, group=group)
-    dist.all_gather_into_tensor(out[2], found, group=group)
-    return out
+    Q, K = hits.shape[0], hits.shape[1]
+    block = alloc_packed(Q, K, hits.device)
+    bh, bn, bf = packed_views(block, Q, K)
+    bh[0].copy_(hits); bn[0].copy_(nhits); bf[0].copy_(found)
+    gathered = torch.empty(world * block.numel(), dtype=torch.uint8, device=hits.device)
+    gather_packed(block, gathered, group=group)
+    gh, gn, gf = packed_views(gathered, Q, K, world)
+    res = (gh.reshape(world * Q, K, 3), gn.reshape(world * Q), gf.reshape(world * Q))
+    if out is not None:
+        out[0].copy_(res[0]); out[1].copy_(res[1]); out[2].copy_(res[2])
+        return out
+    return tuple(t.contiguous() for t in res)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -43,16 +43,16 @@ L.ns_ctx_set_host_threads(eng.ctx, 0)
 # batches alternating between two streams (ns_ctx_set_overlap): the tail of batch i overlaps the head of batch i+1
 for nq in (16384, 4096, 2048, 1024, 256):
     qd_s, refs_s, _ = eng.build_refs(qs[:nq])
-    for overlap in (0, 1):
+    for overlap, depth in ((0, 2), (0, 3), (1, 2), (1, 3), (1, 4)):
         L.ns_ctx_set_overlap(eng.ctx, overlap)
         n = max(24, 65536 // nq)
-        for _ in nsbind.pipelined_search(eng.ctx, [(qd_s, refs_s)] * 6, 10, out=out):
+        for _ in nsbind.pipelined_search(eng.ctx, [(qd_s, refs_s)] * 6, 10, out=out, depth=depth):
             pass
         t0 = time.perf_counter()
-        for _ in nsbind.pipelined_search(eng.ctx, [(qd_s, refs_s)] * n, 10, out=out):
+        for _ in nsbind.pipelined_search(eng.ctx, [(qd_s, refs_s)] * n, 10, out=out, depth=depth):
             pass
         dt = time.perf_counter() - t0
-        print(f"batches of {nq} queries, overlap {overlap}: pipelined host->host {1e3 * dt / n:.3f} ms per batch = {nq * n / dt:.0f} q/s")
+        print(f"batches of {nq} queries, overlap {overlap}, {depth} in flight: pipelined host->host {1e3 * dt / n:.3f} ms per batch = {nq * n / dt:.0f} q/s")
 L.ns_ctx_set_overlap(eng.ctx, 0)
 # query TEXT in -> /api/search JSON bodies out (result assembly incl. metadata.csv decoration when the file is there)
 import workloads as _w  # noqa: E402
