@@ -40,6 +40,7 @@ extern "C" {
 #define NS_FLAG_OR      0u   /* reference semantics: every touched doc is a candidate (src/api_engine.cpp:449-492) */
 #define NS_FLAG_AND     1u   /* extension (BASELINE config 2): keep docs matched by every term ref of their segment */
 #define NS_INFO_IMPACTS 0x100u /* ns_batch_info.flags only (output): the batch reads impact streams (ns_segment_build_impacts) */
+#define NS_INFO_PACKED  0x200u /* ns_batch_info.flags only (output): the batch's driver streams read the packed posting blocks (ns_segment_build_packed) */
 
 typedef struct ns_ctx   ns_ctx;
 typedef struct ns_seg   ns_seg;
@@ -138,6 +139,20 @@ int ns_ctx_set_overlap(ns_ctx* ctx, int on);
  * descriptors): 0 = automatic (up to 8, one per ~1500 queries), 1 = the calling thread only.  The prepared batch — every
  * descriptor byte and the launch order — does not depend on this number. */
 int ns_ctx_set_host_threads(ns_ctx* ctx, uint32_t n);
+/* Compressed, blocked posting stream of a segment, loaded NEXT TO the reference's raw format
+ * (src/lexicon.cpp:104-128: {u32 docId, u32 tf} per posting) and built from it on the device, once:
+ *   blocks of 256 postings; per block a base docId and a width code; per posting a docId offset of 8, 16 or 32 bits
+ *   (frame of reference: whatever the block's doc span needs), tf in 8 bits (255 = escape to the raw stream) and a
+ *   16-bit index into the segment's table of DISTINCT BM25 norms — the norm is a function of doc_len alone, so the
+ *   index loses nothing; the per-posting fp32 norm stream (4 B) is not read at all.
+ * 4 B (dense lists), 5 B or 7 B per posting are read instead of 12; results are bit-identical (same operations on the
+ * same values; every test runs both ways).  `found` (src/api_engine.cpp:495) needs every posting visited, so this is
+ * compression, not skipping.  The scoring kernel's DRIVER streams read the packed blocks (the bulk of the bytes);
+ * foreign windows and doc tiles keep reading the raw stream.  Fails with NS_E_INVAL for a segment with more than
+ * 65536 distinct document lengths.  Costs 8 B of HBM per posting (fixed 2 KB stride per block). */
+int ns_segment_build_packed(ns_ctx* ctx, ns_seg* seg);
+/* on = 0: batches prepared from now on ignore packed streams (default: on = 1: used when every segment of the batch has one). */
+int ns_ctx_use_packed(ns_ctx* ctx, int on);
 /* on = 0: batches prepared from now on ignore impact streams (default: on = 1). */
 int ns_ctx_use_impacts(ns_ctx* ctx, int on);
 

@@ -103,7 +103,14 @@ struct ns_seg {
     void* pin[2] = {nullptr, nullptr};
     hipEvent_t ev[2] = {nullptr, nullptr};
     int stage_k = 0;
-    void* d_packed = nullptr;   // reserved for the packed posting stream (ns_segment_build_packed)
+    // packed posting stream (ns_segment_build_packed; ns_internal.h kPk*): blocks, per-block headers; the norm index per
+    // doc and the table of distinct norms are made at upload (they only exist when the segment has <= 65536 distinct doc lengths)
+    uint32_t* d_packed = nullptr;
+    uint2* d_pk_hdr = nullptr;
+    float* d_pk_scores = nullptr;   // per posting: the impact stream's score alone (built when both streams exist)
+    uint16_t* d_nidx = nullptr;
+    float* d_ntab = nullptr;
+    uint32_t n_norms = 0;
     // Optional impact stream (ns_segment_build_impacts): {docId, term score bits} per posting of the registered lists,
     // index-aligned with d_postings.  `imp_tab`: open-addressed (first posting index -> count, idf bits) of those lists.
     uint2* d_impacts = nullptr;
@@ -156,6 +163,7 @@ struct ns_ctx {
     struct DownSlot { void* p = nullptr; size_t cap = 0; bool busy = false; };
     std::vector<DownSlot> down_slots;
     bool use_impacts = true;   // batches take the impact stream when every list they touch has one (ns_ctx_use_impacts)
+    bool use_packed = true;    // batches read the packed stream when every segment they touch has one (ns_ctx_use_packed)
     ns_prep* prep = nullptr;   // ns_batch_prepare's host threads and per-thread scratch, kept from batch to batch
     unsigned prep_threads = 0; // 0 = automatic (up to 8); 1 = prepare on the calling thread only (ns_ctx_set_host_threads)
 };
@@ -336,7 +344,12 @@ static void seg_free_device(ns_seg* s) {
     (void)hipFree(s->d_pnorm);
     (void)hipFree(s->d_impacts);
     (void)hipFree(s->d_packed);
+    (void)hipFree(s->d_pk_hdr);
+    (void)hipFree(s->d_pk_scores);
+    (void)hipFree(s->d_nidx);
+    (void)hipFree(s->d_ntab);
     s->d_postings = nullptr; s->d_norm = nullptr; s->d_pnorm = nullptr; s->d_impacts = nullptr; s->d_packed = nullptr;
+    s->d_pk_hdr = nullptr; s->d_pk_scores = nullptr; s->d_nidx = nullptr; s->d_ntab = nullptr;
 }
 // host bytes -> device through the segment's two pinned buffers
 static hipError_t seg_stage(ns_ctx* ctx, ns_seg* s, void* dst, const void* src, size_t n) {
@@ -394,6 +407,50 @@ extern "C" int ns_segment_upload_begin(ns_ctx* ctx, uint32_t seg_id, uint32_t n_
     if (e == hipSuccess && n_docs) {
         hipLaunchKernelGGL(k_norm, dim3((n_docs + 255) / 256), dim3(256), 0, ctx->stream, s->d_len, s->d_norm, n_docs, avgdl);
         e = hipGetLastError();
+    }
+    if (e == hipSuccess && n_docs) {
+        // The packed stream's norm plane: a posting carries a 16-bit index into the table of the segment's DISTINCT norms
+        // (norm is a function of doc_len alone) instead of the fp32 norm — no quantisation, 2 B instead of 4.  The table is
+        // k_norm over the distinct lengths: the same expression on the same inputs, the same bits.  Segments with more
+        // than 65536 distinct lengths get no table (and no packed stream).
+        uint32_t max_len = 0;
+        for (uint32_t i = 0; i < n_docs; i++) max_len = std::max(max_len, doc_len[i]);
+        std::vector<uint32_t> uniq;
+        std::vector<uint16_t> nidx;
+        if (max_len < (1u << 24)) {
+            std::vector<uint32_t> rank((size_t)max_len + 1, 0u);
+            for (uint32_t i = 0; i < n_docs; i++) rank[doc_len[i]] = 1u;
+            for (uint32_t v = 0; v <= max_len; v++)
+                if (rank[v]) { rank[v] = (uint32_t)uniq.size(); uniq.push_back(v); }
+            if (uniq.size() <= 65536) {
+                nidx.resize(n_docs);
+                for (uint32_t i = 0; i < n_docs; i++) nidx[i] = (uint16_t)rank[doc_len[i]];
+            }
+        } else {
+            uniq.assign(doc_len, doc_len + n_docs);
+            std::sort(uniq.begin(), uniq.end());
+            uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+            if (uniq.size() <= 65536) {
+                nidx.resize(n_docs);
+                for (uint32_t i = 0; i < n_docs; i++) nidx[i] = (uint16_t)(std::lower_bound(uniq.begin(), uniq.end(), doc_len[i]) - uniq.begin());
+            }
+        }
+        if (!nidx.empty()) {
+            uint32_t* d_ulen = nullptr;
+            const size_t D = uniq.size();
+            e = hipMalloc((void**)&s->d_nidx, (size_t)n_docs * 2);
+            if (e == hipSuccess) e = hipMalloc((void**)&s->d_ntab, D * 4);
+            if (e == hipSuccess) e = hipMalloc((void**)&d_ulen, D * 4);
+            if (e == hipSuccess) e = seg_stage(ctx, s, s->d_nidx, nidx.data(), (size_t)n_docs * 2);
+            if (e == hipSuccess) e = seg_stage(ctx, s, d_ulen, uniq.data(), D * 4);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_norm, dim3((uint32_t)((D + 255) / 256)), dim3(256), 0, ctx->stream, d_ulen, s->d_ntab, (uint32_t)D, avgdl);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // d_ulen and the host vectors die here
+            (void)hipFree(d_ulen);
+            s->n_norms = (uint32_t)D;
+        }
     }
     if (e != hipSuccess) { (void)hipStreamSynchronize(ctx->stream); cleanup(); return fail(ctx, NS_E_HIP, "segment upload: %s", hipGetErrorString(e)); }
     {
@@ -469,6 +526,22 @@ extern "C" int ns_segment_release(ns_ctx* ctx, ns_seg* seg) {
     return NS_OK;
 }
 
+__global__ void __launch_bounds__(256) k_pk_scores(const uint2* __restrict__ impacts, float* __restrict__ scores, uint64_t n) {
+    for (uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x; p < n; p += (uint64_t)gridDim.x * 256) scores[p] = __uint_as_float(impacts[p].y);
+}
+// the packed form of the impact stream = the scores alone, per posting (the docIds come from the packed doc plane)
+static hipError_t seg_fill_pk_scores(ns_ctx* ctx, ns_seg* seg) {
+    if (!seg->d_packed || !seg->d_impacts || !seg->n_postings) return hipSuccess;
+    const uint64_t n = seg->n_postings + kPadPostings;
+    hipError_t e = hipSuccess;
+    if (!seg->d_pk_scores) e = hipMalloc((void**)&seg->d_pk_scores, n * 4);
+    if (e != hipSuccess) { seg->d_pk_scores = nullptr; return e; }
+    hipLaunchKernelGGL(k_pk_scores, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 1u << 16)), dim3(256), 0, ctx->stream, seg->d_impacts, seg->d_pk_scores, n);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    return e;
+}
+
 // One thread per posting: the list that holds it is found by binary search over the (sorted) list starts.
 // The arithmetic is src/api_engine.cpp:477-479 operation for operation with the compiler's IEEE division —
 // the expression the scoring kernels evaluate per posting per query when no impact stream exists.
@@ -536,6 +609,7 @@ extern "C" int ns_segment_build_impacts(ns_ctx* ctx, ns_seg* seg, const uint64_t
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_tmp);
+    if (e == hipSuccess) e = seg_fill_pk_scores(ctx, seg);
     if (e != hipSuccess) return fail(ctx, NS_E_HIP, "ns_segment_build_impacts: %s", hipGetErrorString(e));
     // registry: old entries + new ones (a list given again replaces its entry)
     std::vector<ns_seg::ImpList> all;
@@ -553,6 +627,38 @@ extern "C" int ns_segment_build_impacts(ns_ctx* ctx, ns_seg* seg, const uint64_t
     }
     seg->imp_tab.swap(tab);
     seg->imp_lists = distinct;
+    return NS_OK;
+}
+
+extern "C" int ns_segment_build_packed(ns_ctx* ctx, ns_seg* seg) {
+    if (!ctx || !seg) return fail(ctx, NS_E_INVAL, "ns_segment_build_packed: null argument");
+    if (seg->pending || seg->id >= ctx->segs.size() || ctx->segs[seg->id] != seg) return fail(ctx, NS_E_INVAL, "segment does not belong to this ctx");
+    if (seg->d_packed || !seg->n_postings) return NS_OK;
+    if (!seg->d_nidx) return fail(ctx, NS_E_INVAL, "ns_segment_build_packed: segment %u has more than 65536 distinct document lengths; its norms do not fit a 16-bit index", seg->id);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint64_t n_blocks = (seg->n_postings + kPkBlock - 1) / kPkBlock;
+    hipError_t e = hipMalloc((void**)&seg->d_packed, (n_blocks + 2) * kPkStrideDwords * 4);   // + slack: a round may be planned one block past the end
+    if (e == hipSuccess) e = hipMalloc((void**)&seg->d_pk_hdr, (n_blocks + 2) * sizeof(uint2));
+    if (e == hipSuccess) e = hipMemsetAsync(seg->d_packed + n_blocks * kPkStrideDwords, 0, 2 * kPkStrideDwords * 4, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(seg->d_pk_hdr + n_blocks, 0, 2 * sizeof(uint2), ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_pack, dim3((uint32_t)n_blocks), dim3(64), 0, ctx->stream, seg->d_postings, seg->d_nidx, seg->d_packed, seg->d_pk_hdr,
+                           seg->n_postings, seg->n_docs, (uint32_t)n_blocks);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = seg_fill_pk_scores(ctx, seg);
+    if (e != hipSuccess) {
+        (void)hipFree(seg->d_packed); (void)hipFree(seg->d_pk_hdr);
+        seg->d_packed = nullptr; seg->d_pk_hdr = nullptr;
+        return fail(ctx, e == hipErrorOutOfMemory ? NS_E_NOMEM : NS_E_HIP, "ns_segment_build_packed: %s", hipGetErrorString(e));
+    }
+    return NS_OK;
+}
+
+extern "C" int ns_ctx_use_packed(ns_ctx* ctx, int on) {
+    if (!ctx) return NS_E_INVAL;
+    ctx->use_packed = on != 0;
     return NS_OK;
 }
 
@@ -588,6 +694,7 @@ struct ns_batch {
     uint32_t n_terms = 0, n_parts = 0;
     uint64_t postings = 0;
     bool direct = false;   // every query has exactly one work item: the scoring kernel writes final rows
+    bool pk = false;       // every segment of the batch has a packed posting stream: the driver streams read it (ns_segment_build_packed)
     bool imp = false;      // every list of the batch has an impact stream: the kernels read {docId, score} instead of {docId, tf} + norm
     // device
     DevItem* d_items = nullptr;
@@ -718,7 +825,7 @@ struct PrepSlice {
     std::vector<uint32_t> qgroup_begin;   // q1 - q0 + 1 entries, local group indices
     std::vector<uint32_t> seg_ids;
     uint64_t bounds_total = 0, postings_total = 0, total_work = 0;
-    bool all_imp = true;
+    bool all_imp = true, all_pk = true;
     int err_code = NS_OK;
     uint32_t err_query = 0xFFFFFFFFu;
     std::string err_msg;
@@ -738,7 +845,7 @@ struct PrepSlice {
     void reset(uint32_t a, uint32_t b) {
         q0 = a; q1 = b;
         dterms.clear(); groups.clear(); qgroup_begin.clear(); seg_ids.clear();
-        bounds_total = postings_total = total_work = 0; all_imp = true;
+        bounds_total = postings_total = total_work = 0; all_imp = true; all_pk = true;
         err_code = NS_OK; err_query = 0xFFFFFFFFu; err_msg.clear();
         witems.clear(); wbucket.clear(); items.clear(); item_cost.clear(); bgroups.clear();
         n_rows = 0; direct = true;
@@ -789,6 +896,10 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
             d.postings = s->d_postings;
             d.pnorm = s->d_pnorm;
             d.impacts = s->d_impacts;
+            d.packed = s->d_packed;
+            d.pk_hdr = s->d_pk_hdr;
+            d.ntab = s->d_ntab;
+            d.pk_scores = s->d_pk_scores;
             d.norm = s->d_norm;
             d.n_postings = s->n_postings;
             d.n_docs = s->n_docs;
@@ -837,6 +948,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
             for (uint32_t sid : S.seg_ids) {
                 HostGroup hg{};
                 hg.fast_div = ctx->segs[sid]->norm_safe;
+                if (!ctx->segs[sid]->d_packed) S.all_pk = false;
                 hg.g.term_begin = (uint32_t)S.dterms.size();   // local to the slice until phase B
                 hg.g.seg = sid;
                 hg.query = q;
@@ -897,13 +1009,14 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
     }
     uint64_t bounds_total = 0, postings_total = 0, total_work = 0;
     uint32_t n_dterms = 0, G = 0;
-    bool all_imp = want_imp;
+    bool all_imp = want_imp, all_pk = ctx->use_packed && auto_mode;
     for (unsigned s = 0; s < width; s++) {
         PrepSlice& S = P.slices[s];
         S.term_off = n_dterms; S.bounds_off = bounds_total;
         n_dterms += (uint32_t)S.dterms.size(); G += (uint32_t)S.groups.size();
         bounds_total += S.bounds_total; postings_total += S.postings_total; total_work += S.total_work;
         all_imp = all_imp && S.all_imp;
+        all_pk = all_pk && S.all_pk;
     }
     if (bounds_total >= (1ull << 32)) return fail(ctx, NS_E_INVAL, "batch too large: %llu boundary entries; split the batch", (unsigned long long)bounds_total);
 
@@ -1045,6 +1158,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
     b->postings = postings_total;
     b->direct = direct;
     b->imp = all_imp && postings_total > 0;
+    b->pk = all_pk && postings_total > 0;
 
     // queries cut into many partial rows: joined by k_merge_wide, one workgroup each
     std::vector<uint32_t> wide_q;
@@ -1215,14 +1329,18 @@ extern "C" int ns_batch_run(ns_batch* b, int run_flags) {
         // K <= 64: a 128-entry candidate buffer is enough (K + 64 appended per step at most) and its
         // smaller LDS footprint admits more workgroups per CU.  Groups of <= 16 terms (all but exotic
         // queries) run in the instantiation with 16-entry term tables; the rest in the 64-entry one.
-#define NS_U(CBV, TM, N, PTR)                                                                                      \
+#define NS_U2(CBV, TM, N, PTR, IMPV, PKV)                                                                         \
         {                                                                                                          \
             dim3 g_(((N) + kUscoreWavesPerBlock - 1) / kUscoreWavesPerBlock);                                     \
-            if (b->imp) {                                                                                          \
-                if (and_mode) hipLaunchKernelGGL((k_uscore<512, 192, true, CBV, TM, true>), g_, block, 0, st, (PTR), (N), b->d_terms, b->d_segs, sh, sn, sf, b->K); \
-                else hipLaunchKernelGGL((k_uscore<512, 192, false, CBV, TM, true>), g_, block, 0, st, (PTR), (N), b->d_terms, b->d_segs, sh, sn, sf, b->K);         \
-            } else if (and_mode) hipLaunchKernelGGL((k_uscore<512, 192, true, CBV, TM>), g_, block, 0, st, (PTR), (N), b->d_terms, b->d_segs, sh, sn, sf, b->K); \
-            else hipLaunchKernelGGL((k_uscore<512, 192, false, CBV, TM>), g_, block, 0, st, (PTR), (N), b->d_terms, b->d_segs, sh, sn, sf, b->K);         \
+            if (and_mode) hipLaunchKernelGGL((k_uscore<512, 192, true, CBV, TM, IMPV, PKV>), g_, block, 0, st, (PTR), (N), b->d_terms, b->d_segs, sh, sn, sf, b->K); \
+            else hipLaunchKernelGGL((k_uscore<512, 192, false, CBV, TM, IMPV, PKV>), g_, block, 0, st, (PTR), (N), b->d_terms, b->d_segs, sh, sn, sf, b->K);         \
+        }
+#define NS_U(CBV, TM, N, PTR)                                                                                      \
+        {                                                                                                          \
+            if (b->imp && b->pk) NS_U2(CBV, TM, N, PTR, true, true)                                                \
+            else if (b->imp) NS_U2(CBV, TM, N, PTR, true, false)                                                   \
+            else if (b->pk) NS_U2(CBV, TM, N, PTR, false, true)                                                    \
+            else NS_U2(CBV, TM, N, PTR, false, false)                                                              \
         }
         const uint32_t n_narrow = b->n_class[0], n_wide = b->n_witems - b->n_class[0];
         (void)grid;
@@ -1234,6 +1352,7 @@ extern "C" int ns_batch_run(ns_batch* b, int run_flags) {
             if (n_wide) NS_U(256, 64, n_wide, b->d_witems + n_narrow);
         }
 #undef NS_U
+#undef NS_U2
     } else if (b->n_witems) {
         const VariantDesc wv = kVariants[b->variant];
 #define NS_D(HH, FF) launch_dscore<HH, FF>(and_mode, b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K)
@@ -1402,7 +1521,7 @@ extern "C" int ns_batch_get_info(ns_batch* b, ns_batch_info* info) {
     info->n_term_refs = b->n_terms;
     info->tile_docs = b->tile_docs;
     info->k = b->K;
-    info->flags = b->flags | (b->imp ? NS_INFO_IMPACTS : 0u);
+    info->flags = b->flags | (b->imp ? NS_INFO_IMPACTS : 0u) | (b->pk ? NS_INFO_PACKED : 0u);
     info->last_score_kernel_ms = b->last_score_ms;
     info->last_total_ms = b->last_total_ms;
     info->timed_runs = b->timed_runs;

@@ -41,7 +41,62 @@ __device__ unsigned long long g_ns_cnt[16];
 // NB  buckets of 4 entries per wave   FB  foreign postings per super-batch (<= 256: the owner index has 8 bits).
 // A driver lookup reads ONE bucket and stops unless the bucket is full and holds no match: with FB/NB <= 0.75
 // a full bucket is a < 1% event, so practically every lookup is a single ds_read_b128 for all 64 lanes.
-template <int NB, int FB, bool AND, int CB = 256, bool IMP = false>
+// One round of the PACKED posting stream (ns_internal.h kPk*): block `blk` of the segment, decoded into the same
+// registers a raw round fills — docIds, tf as float (or the precomputed score bits when IMP), norms.  Wave-uniform
+// control: the block header comes through scalar loads, the width code selects one of three decode paths.
+template <bool IMP>
+__device__ __forceinline__ void pk_decode_round(const DevSeg& seg, const uint32_t blk, const int lane, uint32_t (&doc)[4], float (&tf)[4],
+                                                float (&nr)[4], uint32_t (&sbits)[4]) {
+    typedef const __attribute__((address_space(1))) uint32_t* gp_u32;
+    const uint2 hd = seg.pk_hdr[blk];                                   // uniform address: scalar load
+    const uint32_t base = __builtin_amdgcn_readfirstlane((int)hd.x);
+    const uint32_t code = __builtin_amdgcn_readfirstlane((int)hd.y);
+    const gp_u32 pb = (gp_u32)seg.packed + (size_t)blk * kPkStrideDwords + (uint32_t)lane;
+    if (code == 0u) {
+        const uint32_t d = pb[kPkDoc];
+#pragma unroll
+        for (int c = 0; c < 4; c++) doc[c] = base + ((d >> (8 * c)) & 255u);
+    } else if (code == 1u) {
+        const uint32_t d0 = pb[kPkDoc], d1 = pb[kPkDoc + 64];
+        doc[0] = base + (d0 & 0xFFFFu); doc[1] = base + (d0 >> 16);
+        doc[2] = base + (d1 & 0xFFFFu); doc[3] = base + (d1 >> 16);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; c++) doc[c] = pb[kPkDoc + c * 64];
+    }
+    if (IMP) {
+        const gp_f32 sc = (gp_f32)seg.pk_scores + (size_t)blk * kPkBlock + (uint32_t)lane;
+#pragma unroll
+        for (int c = 0; c < 4; c++) { sbits[c] = __float_as_uint(sc[c * 64]); tf[c] = 0.0f; nr[c] = 0.0f; }
+    } else {
+        const uint32_t t = pb[kPkTf], na = pb[kPkNormA], nb = pb[kPkNormB];
+        const gp_f32 ntab = (gp_f32)seg.ntab;
+        uint32_t tfi[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) tfi[c] = (t >> (8 * c)) & 255u;
+        // tf >= 255 is stored as the escape 255: the true count is in the raw stream (rare: one test per round)
+        const uint32_t nt_ = ~t;
+        if (wballot(((nt_ - 0x01010101u) & t & 0x80808080u) != 0u) != 0ull) {   // some byte of t is 0xFF  <=>  some byte of ~t is zero
+            const gp_u2 raw = (gp_u2)seg.postings + (size_t)blk * kPkBlock + (uint32_t)lane;
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                if (tfi[c] == 255u) { const nat_u2 pv = raw[c * 64]; tfi[c] = pv.y; }
+        }
+        nr[0] = ntab[na & 0xFFFFu]; nr[1] = ntab[na >> 16];
+        nr[2] = ntab[nb & 0xFFFFu]; nr[3] = ntab[nb >> 16];
+#pragma unroll
+        for (int c = 0; c < 4; c++) { tf[c] = (float)tfi[c]; sbits[c] = 0u; }
+    }
+}
+
+// lanes [lo, hi) of a 64-lane chunk as a mask (lo <= hi <= 64), scalar arithmetic
+__device__ __forceinline__ uint64_t lane_span(uint32_t lo, uint32_t hi) {
+    const uint64_t upto_hi = hi >= 64u ? ~0ull : ((1ull << hi) - 1ull);
+    const uint64_t upto_lo = lo >= 64u ? ~0ull : ((1ull << lo) - 1ull);
+    return upto_hi & ~upto_lo;
+}
+
+template <int NB, int FB, bool AND, int CB = 256, bool IMP = false, bool PK = false>
 __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* __restrict__ terms, const DevSeg* __restrict__ segs,
                                             uint32_t* ent, float* vals, uint8_t* mcnt, uint64_t* cand, uint4* tab, uint32_t* aux,
                                             Hit* __restrict__ out_hits, uint32_t* __restrict__ out_nhits,
@@ -409,41 +464,69 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
         for (;;) {
             const uint32_t remd = d_end - d_cur;
             if (remd == 0) break;
-            const uint32_t n = min(remd, (uint32_t)(DE * 64));
-            const gp_u2 sp = stream + d_cur;
-            const gp_f32 np = pnorm + d_cur;
+            uint32_t n;
             nat_u2 ps[DE];
             float nr[DE];
-#pragma unroll
-            for (int j = 0; j < DE; j++) {
-                ps[j] = sp[j * 64 + lane];
-                nr[j] = IMP ? 0.0f : np[j * 64 + lane];
-            }
+            float tfv[DE];
+            uint32_t sbits[DE];
             uint32_t cnt = 0, r_hits = 0;
-            NS_CNT(8, 1);                       // driver rounds (256 postings loaded each)
-            NS_CNT(12, (n + 63) / 64);          // driver chunks with postings
+            NS_CNT(8, 1);                       // driver rounds (256 loaded each)
             float dx[DE];
             uint64_t dokm[DE];   // postings of this round that belong to the super-batch and are still private
-            if (n == (uint32_t)(DE * 64)) {   // a full round (all but a list's last): no lane mask to build
+            uint32_t first_pos, last_pos;       // PK: positions (0..255) of the round's first / last valid posting inside its block
+            if (PK) {
+                // the packed stream comes in blocks of 256 postings of the segment's posting index space: a round is the
+                // part [a, e) of the block that holds the cursor (the cursor moves by what is consumed, so a block may be
+                // decoded again by the next super-batch, as a raw round may be loaded again)
+                static_assert(DE == 4, "a packed round is one block of 4 chunks");
+                const uint32_t blk = d_cur >> 8;
+                const uint32_t a = d_cur & 255u;
+                const uint32_t e = min(256u, d_end - (blk << 8));
+                n = e - a;
+                first_pos = a; last_pos = e - 1u;
+                uint32_t docs_[4];
+                pk_decode_round<IMP>(seg, blk, lane, docs_, tfv, nr, sbits);
 #pragma unroll
                 for (int j = 0; j < DE; j++) {
-                    dokm[j] = wballot(ps[j].x <= hi);
+                    ps[j].x = docs_[j]; ps[j].y = sbits[j];
+                    const uint32_t c0 = (uint32_t)(j * 64);
+                    const uint64_t vm = lane_span(a > c0 ? a - c0 : 0u, e > c0 ? min(e - c0, 64u) : 0u);
+                    dokm[j] = wballot(ps[j].x <= hi) & vm;
                     cnt += (uint32_t)__popcll(dokm[j]);
                 }
             } else {
+                n = min(remd, (uint32_t)(DE * 64));
+                first_pos = 0u; last_pos = n - 1u;
+                const gp_u2 sp = stream + d_cur;
+                const gp_f32 np = pnorm + d_cur;
 #pragma unroll
                 for (int j = 0; j < DE; j++) {
-                    const uint32_t left = (n > (uint32_t)(j * 64)) ? (n - (uint32_t)(j * 64)) : 0u;   // scalar
-                    const uint64_t nmask = (left >= 64u) ? ~0ull : ((1ull << left) - 1ull);
-                    dokm[j] = wballot(ps[j].x <= hi) & nmask;
-                    cnt += (uint32_t)__popcll(dokm[j]);
+                    ps[j] = sp[j * 64 + lane];
+                    nr[j] = IMP ? 0.0f : np[j * 64 + lane];
+                    tfv[j] = (float)ps[j].y;
+                }
+                if (n == (uint32_t)(DE * 64)) {   // a full round (all but a list's last): no lane mask to build
+#pragma unroll
+                    for (int j = 0; j < DE; j++) {
+                        dokm[j] = wballot(ps[j].x <= hi);
+                        cnt += (uint32_t)__popcll(dokm[j]);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < DE; j++) {
+                        const uint32_t left = (n > (uint32_t)(j * 64)) ? (n - (uint32_t)(j * 64)) : 0u;   // scalar
+                        const uint64_t nmask = (left >= 64u) ? ~0ull : ((1ull << left) - 1ull);
+                        dokm[j] = wballot(ps[j].x <= hi) & nmask;
+                        cnt += (uint32_t)__popcll(dokm[j]);
+                    }
                 }
             }
+            NS_CNT(12, (n + 63) / 64);          // driver chunks with postings
             {   // src/api_engine.cpp:477-480, operation for operation
                 float num[DE], den[DE];
 #pragma unroll
                 for (int j = 0; j < DE; j++) {
-                    const float tf = (float)ps[j].y;
+                    const float tf = tfv[j];
                     den[j] = tf + nr[j];
                     num[j] = d_idf * (tf * (1.2f + 1.0f));
                 }
@@ -467,11 +550,12 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
             // not when the driver is much denser than the foreign lists: then the lookups are skipped)
             bool any_foreign_here = total > 0;
             if (FB <= 64 && total > 0) {   // only worth testing for the thin-foreign class
-                const uint32_t rfirst = rdlane(ps[0].x, 0);
-                uint32_t rlast = 0;
+                uint32_t rfirst = 0, rlast = 0;
 #pragma unroll
-                for (int j = 0; j < DE; j++)
-                    if (((n - 1u) >> 6) == (uint32_t)j) rlast = rdlane(ps[j].x, (n - 1u) & 63u);   // uniform
+                for (int j = 0; j < DE; j++) {   // uniform selects
+                    if ((first_pos >> 6) == (uint32_t)j) rfirst = rdlane(ps[j].x, first_pos & 63u);
+                    if ((last_pos >> 6) == (uint32_t)j) rlast = rdlane(ps[j].x, last_pos & 63u);
+                }
                 bool here = false;
 #pragma unroll
                 for (int j = 0; j < FE; j++) here = here || (fok[j] && fdoc[j] >= rfirst && fdoc[j] <= rlast);
@@ -482,7 +566,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
                 // the term order (foreign terms before it are already in, those after it follow)
 #pragma unroll
                 for (int j = 0; j < DE; j++) {
-                    if ((uint32_t)(j * 64) >= n) continue;   // uniform
+                    if (PK ? ((uint32_t)(j * 64) > last_pos || (uint32_t)(j * 64 + 63) < first_pos) : ((uint32_t)(j * 64) >= n)) continue;   // uniform: no posting of this round in the chunk
                     const uint32_t tag = NS_TAG(ps[j].x);
                     uint32_t b = ps[j].x & (uint32_t)(NB - 1);
                     uint4 q = ent4[b];

@@ -14,11 +14,31 @@ namespace ns {
 // counts the doc and starts from +0.0f.  (fp32 arithmetic on finite or infinite inputs never produces this payload;
 // an idf or weight that is itself this NaN is outside what the engine can pass.)
 static constexpr uint32_t kTileEmptyBits = 0xFFFFFFFFu;
+// Packed posting block (f2): 256 postings, stored as byte/halfword PLANES so that one dword load per lane fetches the
+// same field of the lane's postings in all four 64-posting chunks (lane l <-> postings l, 64 + l, 128 + l, 192 + l of the block):
+//   dword   0 ..  63   tf plane      byte c = min(tf, 255) of chunk c          (255: take tf from the raw stream)
+//   dword  64 .. 127   norm plane A  low half = norm index of chunk 0, high half = chunk 1
+//   dword 128 .. 191   norm plane B  chunks 2, 3
+//   dword 192 ..       doc plane     code 0: one dword, byte c = docId - base of chunk c        (block spans < 256 docs)
+//                                    code 1: two dwords (chunks 0|1, chunks 2|3), 16-bit offsets (block spans < 65536 docs)
+//                                    code 2: four dwords, the docIds themselves
+// i.e. 4 B (code 0), 5 B (code 1) or 7 B (code 2) per posting are READ; every block owns kPkStrideDwords dwords so that
+// block b sits at b * stride (HBM footprint is not what this format saves; bytes moved per posting are).
+static constexpr uint32_t kPkBlock = 256;
+static constexpr uint32_t kPkStrideDwords = 512;   // 2 KB
+static constexpr uint32_t kPkTf = 0, kPkNormA = 64, kPkNormB = 128, kPkDoc = 192;
+
 struct DevSeg {
     const uint2* postings;   // {docId, tf} pairs, all inverted files of the segment back to back
     const float* pnorm;      // per POSTING: norm[docId] (streams next to the posting; no dependent gather)
     const float* norm;       // per doc: k1*((1-b) + b*(doc_len/avgdl))   (src/api_engine.cpp:478)
     const uint2* impacts;    // optional {docId, fp32 bits of the BM25 term score}, index-aligned with `postings` (ns_segment_build_impacts); nullptr if never built
+    // optional packed posting stream (ns_segment_build_packed): blocks of 256 postings of the SAME posting
+    // index space as `postings` (block b = postings [256 b, 256 b + 256)), see kPk* below; nullptr if never built
+    const uint32_t* packed;  // kPkStrideDwords dwords per block
+    const uint2* pk_hdr;     // per block: {base docId, doc width code}
+    const float* ntab;       // the segment's distinct norms; a posting carries a 16-bit index into it
+    const float* pk_scores;  // optional, per block 4 x 64 fp32 term scores (chunk-major): the impact stream in packed form
     uint64_t     n_postings;
     uint32_t     n_docs;
     uint32_t     n_tiles;    // ceil(n_docs / tile_docs)

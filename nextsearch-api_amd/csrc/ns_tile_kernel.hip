@@ -344,7 +344,9 @@ __global__ void __launch_bounds__(256) k_tscore(const DevWItem* __restrict__ ite
 // unequal length per workgroup ~12 % of the wave slots sat idle mid-kernel.  One item per workgroup.
 constexpr int kUscoreWavesPerBlock = 1;
 
-template <int HK, int FB, bool AND, int CB, int TMAX, bool IMP = false>
+// PK: the driver stream reads the packed posting blocks (ns_segment_build_packed) instead of {docId, tf} + norm; foreign
+// windows and doc tiles keep reading the raw stream.
+template <int HK, int FB, bool AND, int CB, int TMAX, bool IMP = false, bool PK = false>
 __global__ void __launch_bounds__(64 * kUscoreWavesPerBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) k_uscore(const DevWItem* __restrict__ items, uint32_t n_items,
                                                 const DevTerm* __restrict__ terms, const DevSeg* __restrict__ segs,
                                                 Hit* __restrict__ out_hits, uint32_t* __restrict__ out_nhits,
@@ -365,13 +367,13 @@ __global__ void __launch_bounds__(64 * kUscoreWavesPerBlock) __attribute__((amdg
     const bool thin = (it.whole & 4u) != 0;   // the non-driver lists are thin: smallest foreign budget
     it.whole &= 25u;   // bit 0: whole segment, bit 3: short division, bit 4: signed inputs
     if (thin)
-        dscore_body<HK / 2, 64, AND, CB, IMP>(it, terms, segs, s_tbl[wave], s_vals[wave], s_mcnt[wave], s_cand[wave],
+        dscore_body<HK / 2, 64, AND, CB, IMP, PK>(it, terms, segs, s_tbl[wave], s_vals[wave], s_mcnt[wave], s_cand[wave],
                                  s_tab[wave], s_aux[wave], out_hits, out_nhits, out_found, K, lane);
     else if (tiles)
         tscore_body<2 * HK, AND, CB, IMP>(it, terms, segs, reinterpret_cast<float*>(s_tbl[wave]), s_mcnt[wave], s_cand[wave],
                                  out_hits, out_nhits, out_found, K, lane);
     else
-        dscore_body<HK / 2, FB, AND, CB, IMP>(it, terms, segs, s_tbl[wave], s_vals[wave], s_mcnt[wave], s_cand[wave],
+        dscore_body<HK / 2, FB, AND, CB, IMP, PK>(it, terms, segs, s_tbl[wave], s_vals[wave], s_mcnt[wave], s_cand[wave],
                                  s_tab[wave], s_aux[wave], out_hits, out_nhits, out_found, K, lane);
 }
 

@@ -273,4 +273,52 @@ __global__ void k_pnorm(const uint2* __restrict__ postings, const float* __restr
     }
 }
 
+// Packed posting stream, built once per segment (ns_segment_build_packed): one wave per block of 256 postings.
+// nidx[doc] = index of the doc's norm in the segment's table of distinct norms (k_norm over the distinct doc lengths:
+// the same expression, the same bits).  A block's doc width follows from the span of its docIds; blocks that straddle
+// two lists (docIds not ascending) simply get the width their span needs.
+__global__ void __launch_bounds__(64) k_pack(const uint2* __restrict__ postings, const uint16_t* __restrict__ nidx,
+                                             uint32_t* __restrict__ packed, uint2* __restrict__ hdr, uint64_t n_postings,
+                                             uint32_t n_docs, uint32_t n_blocks) {
+    const uint32_t b = blockIdx.x;
+    if (b >= n_blocks) return;
+    const uint32_t lane = threadIdx.x;
+    uint32_t doc[4], tf[4], ni[4];
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const uint64_t g = (uint64_t)b * kPkBlock + (uint32_t)c * 64u + lane;
+        doc[c] = 0xFFFFFFFFu; tf[c] = 0; ni[c] = 0;
+        if (g < n_postings) {
+            const uint2 p = postings[g];
+            doc[c] = p.x; tf[c] = p.y;
+            ni[c] = p.x < n_docs ? nidx[p.x] : 0u;
+            mn = min(mn, p.x); mx = max(mx, p.x);
+        }
+    }
+    mn = wave_min_dpp(mn);
+    mx = wave_max_dpp(mx);
+    if (mn > mx) { mn = 0; mx = 0; }   // no posting at all (cannot happen for b < n_blocks)
+    const uint32_t span = mx - mn;
+    const uint32_t code = span < 256u ? 0u : (span < 65536u ? 1u : 2u);
+    const uint32_t base = code == 2u ? 0u : mn;
+    uint32_t* blk = packed + (uint64_t)b * kPkStrideDwords;
+    uint32_t off[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) off[c] = doc[c] == 0xFFFFFFFFu ? 0u : doc[c] - base;   // padding lanes are masked by posting index, never by value
+    blk[kPkTf + lane] = min(tf[0], 255u) | (min(tf[1], 255u) << 8) | (min(tf[2], 255u) << 16) | (min(tf[3], 255u) << 24);
+    blk[kPkNormA + lane] = ni[0] | (ni[1] << 16);
+    blk[kPkNormB + lane] = ni[2] | (ni[3] << 16);
+    if (code == 0u) {
+        blk[kPkDoc + lane] = off[0] | (off[1] << 8) | (off[2] << 16) | (off[3] << 24);
+    } else if (code == 1u) {
+        blk[kPkDoc + lane] = off[0] | (off[1] << 16);
+        blk[kPkDoc + 64 + lane] = off[2] | (off[3] << 16);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; c++) blk[kPkDoc + c * 64 + lane] = doc[c];
+    }
+    if (lane == 0) hdr[b] = make_uint2(base, code);
+}
+
 }  // namespace ns

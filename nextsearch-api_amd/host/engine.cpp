@@ -192,6 +192,19 @@ bool Engine::build_impacts() {
     return true;
 }
 
+// Optional: the compressed, blocked posting stream of every segment (ns_segment_build_packed).
+bool Engine::build_packed() {
+    std::lock_guard<std::recursive_mutex> lock(mtx_);
+    if (!ctx_) { err_ = "no device context"; return false; }
+    for (size_t sid = 0; sid < dev_segs_.size(); sid++) {
+        int rc = ns_segment_build_packed(ctx_, dev_segs_[sid]);
+        if (rc != NS_OK) { err_ = std::string("ns_segment_build_packed: ") + ns_last_error(ctx_); return false; }
+    }
+    return true;
+}
+
+void Engine::use_packed(bool on) { std::lock_guard<std::recursive_mutex> lock(mtx_); if (ctx_) ns_ctx_use_packed(ctx_, on ? 1 : 0); }
+
 void Engine::use_impacts(bool on) { std::lock_guard<std::recursive_mutex> lock(mtx_); if (ctx_) ns_ctx_use_impacts(ctx_, on ? 1 : 0); }
 
 // Query preparation (tokenise, stop-words, lexicon probes, idf: src/api_engine.cpp:388-397,:454-461) for

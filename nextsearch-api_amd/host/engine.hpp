@@ -65,6 +65,11 @@ public:
     // (ns_segment_build_impacts); searches then read {docId, score} instead of {docId, tf} + norm.  Same results.
     bool build_impacts();
     void use_impacts(bool on);
+    // Optional: blocks of 256 postings with 8/16/32-bit docId offsets, 8-bit tf and a 16-bit norm index,
+    // built on the device next to the raw stream (ns_segment_build_packed); the driver streams then read 4-7 B per posting
+    // instead of 12.  Same results.
+    bool build_packed();
+    void use_packed(bool on);
     std::string search(const std::string& query, int k);        // include/api_engine.hpp:66 (JSON text, dump(2) layout)
     // Search-result cache around search() (src/api_engine.cpp:190-250,:380-385,:539): key "query|K", at most 2600
     // entries, least recently used evicted, a hit returns the stored body plus "from_cache": true.  In memory only:

@@ -193,11 +193,16 @@ def test_full_batches_equal_oracle_and_reference_digests(index_factory):
             if "ties" in e:
                 bad = [b for b, (x, y) in enumerate(zip(dig["ties"], e["ties"])) if x != y]
                 assert not bad, f"{cfg}: blocks {bad[:8]} differ from the real reference's tie-invariant digests"
-            # the optional impact stream must not change a byte either
+            # the optional streams (packed blocks, impacts, both) must not change a byte either
+            eng.build_packed()
+            h2, n2, f2, _ = eng.search_batch(gen(Q), K, flags)
+            assert hits.tobytes() == h2.tobytes() and nhits.tobytes() == n2.tobytes() and found.tobytes() == f2.tobytes(), cfg + " packed"
             if cfg in ("cfg5", "cfg3"):
                 eng.build_impacts()
-                h2, n2, f2, _ = eng.search_batch(gen(Q), K, flags)
-                assert hits.tobytes() == h2.tobytes() and nhits.tobytes() == n2.tobytes() and found.tobytes() == f2.tobytes()
+                for pk in (True, False):
+                    eng.use_packed(pk)
+                    h2, n2, f2, _ = eng.search_batch(gen(Q), K, flags)
+                    assert hits.tobytes() == h2.tobytes() and nhits.tobytes() == n2.tobytes() and found.tobytes() == f2.tobytes(), (cfg, "impacts", pk)
         finally:
             eng.close()
 
@@ -598,6 +603,129 @@ def test_impact_stream_equals_oracle_and_reference_golden(name, golden_index):
     finally:
         eng.close()
         ora.close()
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_packed_stream_equals_oracle_and_reference_golden(name, golden_index):
+    """the compressed, blocked posting stream (ns_segment_build_packed: 256-posting blocks, 8/16/32-bit docId
+    offsets, 8-bit tf, 16-bit index into the table of distinct norms) must change nothing: same bytes as the oracle, as
+    the raw stream's answers and as the real reference's captured scores — OR and AND, K = 1/10/100, forced fine splits
+    (cursors land inside blocks), alone and together with the impact stream — and the batches must really read it."""
+    g, d, _ = golden_index(name)
+    eng, ora = nsbind.Engine(d, 0), orc.Oracle(d)
+    try:
+        queries = g["queries"]
+        plain = {k: eng.search_batch(queries, k) for k in (1, 10, 100)}
+        plain_and = eng.search_batch(queries, 10, nsbind.NS_FLAG_AND)
+        b = eng.prepare(queries, 10)
+        assert not (b.info().flags & nsbind.NS_INFO_PACKED)
+        b.close()
+        eng.build_packed()
+        for with_impacts in (False, True):
+            if with_impacts:
+                eng.build_impacts()
+            b = eng.prepare(queries, 10)
+            fl = b.info().flags
+            assert fl & nsbind.NS_INFO_PACKED and bool(fl & nsbind.NS_INFO_IMPACTS) == with_impacts
+            b.close()
+            for k in (1, 10, 100):
+                gpu = eng.search_batch(queries, k)
+                assert_same(gpu, ora.search_batch(queries, k), queries, f"{name} packed k={k} impacts={with_impacts}")
+                for a, c in zip(gpu, plain[k]):
+                    assert a.tobytes() == c.tobytes()
+            for a, c in zip(eng.search_batch(queries, 10, nsbind.NS_FLAG_AND), plain_and):
+                assert a.tobytes() == c.tobytes()
+            for case in g["cases"]:
+                gh, gn, gf, gu = eng.search_batch(queries, case["k"])
+                for qi, ref in enumerate(case["results"]):
+                    if ref["found"] < 0:
+                        continue
+                    assert int(gf[qi]) == ref["found"]
+                    assert [int(x) for x in gh[qi, : gn[qi]]["score"].view(np.uint32)] == [h[2] for h in ref["hits"]]
+            for tune in ((0, 4096, 300), (0, 1, 1 << 30), (0, 20000, 700)):
+                eng.set_tuning(*tune)
+                assert_same(eng.search_batch(queries[:24], 10), ora.search_batch(queries[:24], 10), queries[:24], f"{name} packed split {tune}")
+            eng.set_tuning(0, 0, 0)
+        eng.use_packed(False)
+        b = eng.prepare(queries, 10)
+        assert not (b.info().flags & nsbind.NS_INFO_PACKED)
+        b.close()
+    finally:
+        eng.close()
+        ora.close()
+
+
+def test_packed_stream_escapes_and_limits():
+    """Raw C-ABI on a crafted segment: tf values of 254, 255, 256 and 70000 (the tf plane holds 8 bits; 255 is the escape
+    to the raw stream), lists that start and end in the middle of blocks, a block that straddles three lists (docIds not
+    ascending inside it: 32-bit doc plane), dense runs (8-bit plane) next to sparse ones (16-bit), and a segment with more
+    than 65536 distinct document lengths, for which the packed stream must be refused and the raw path keep working."""
+    L = nsbind.hip_lib()
+    ctx = C.c_void_p()
+    assert L.ns_ctx_create(0, C.byref(ctx)) == 0
+    try:
+        N = 300_000
+        rng = np.random.default_rng(256)
+        doc_len = rng.integers(20, 3000, size=N, dtype=np.uint32)
+        avgdl = float(np.float32(doc_len.astype(np.float64).mean()))
+        specs = [("dense", np.arange(1000, 1000 + 700)), ("sparse", np.sort(rng.choice(N, 900, replace=False))), ("tiny", np.array([5, 70000, 299999])),
+                 ("mid", np.sort(rng.choice(60000, 5000, replace=False))), ("tiny2", np.array([9])), ("wide", np.sort(rng.choice(N, 300, replace=False)))]
+        lists, payload = [], []
+        for i, (_, docs) in enumerate(specs):
+            docs = docs.astype(np.uint32)
+            tfs = rng.integers(1, 12, size=len(docs), dtype=np.uint32)
+            if len(docs) > 100:
+                tfs[3] = 254; tfs[40] = 255; tfs[41] = 256; tfs[77] = 70000; tfs[len(docs) - 1] = 255
+            lists.append((docs, tfs))
+            payload.append(np.stack([docs, tfs], axis=1).astype(np.uint32).ravel())
+        flat = np.concatenate(payload)
+        offs = np.cumsum([0] + [len(p) * 4 for p in payload])[:-1]
+        seg = C.c_void_p()
+        assert L.ns_segment_upload(ctx, 0, N, C.c_float(avgdl), doc_len.ctypes.data, flat.ctypes.data, flat.nbytes, C.byref(seg)) == 0, L.ns_last_error(ctx)
+        idfs = [1.25, 2.5, 6.0, 1.75, 9.0, 3.5]
+        queries = [[0], [1], [3], [0, 3], [3, 0, 1], [2, 4, 5], [5, 1, 3, 0], [4], [3, 3], [1, 5]]
+        qd = np.zeros(len(queries), dtype=nsbind.QDESC_DTYPE)
+        refs = []
+        for qi, q in enumerate(queries):
+            qd[qi] = (len(refs), len(q))
+            for li in q:
+                refs.append((0, len(lists[li][0]), int(offs[li]), idfs[li], 1.0))
+        refs = np.array(refs, dtype=nsbind.TERM_DTYPE)
+        raw = {k: nsbind.search_batch_raw(ctx, qd, refs, k) for k in (10, 100)}
+        assert L.ns_segment_build_packed(ctx, seg) == 0, L.ns_last_error(ctx)
+        for split in (0, 200, 1 << 30):
+            assert L.ns_set_tuning(ctx, 0, 1 if split else 0, split) == 0
+            for k in (10, 100):
+                b = nsbind.prepare_raw(ctx, qd, refs, k)
+                assert b.info().flags & nsbind.NS_INFO_PACKED
+                b.run(); hits, nhits, found = b.fetch(); b.close()
+                for qi, q in enumerate(queries):
+                    acc = _np_bm25(lists, q, [idfs[li] for li in q], [1.0] * len(q), doc_len, avgdl)
+                    assert int(found[qi]) == len(acc)
+                    order = sorted(acc.items(), key=lambda kv: (-float(kv[1]), kv[0]))[:k]
+                    n = int(nhits[qi])
+                    assert n == len(order) and [int(x) for x in hits[qi, :n]["doc"]] == [dd for dd, _ in order], (split, k, qi)
+                    np.testing.assert_array_equal(hits[qi, :n]["score"].view(np.uint32), np.array([v for _, v in order], dtype=np.float32).view(np.uint32))
+                if split == 0:
+                    for a, c in zip((hits, nhits, found), raw[k][1:]):
+                        assert a.tobytes() == c.tobytes()
+        L.ns_set_tuning(ctx, 0, 0, 0)
+        assert L.ns_segment_release(ctx, seg) == 0
+        # more than 65536 distinct document lengths: no 16-bit norm index, no packed stream; the raw path is unaffected
+        N2 = 70_000
+        dl2 = (np.arange(N2, dtype=np.uint32) + 10)
+        seg2 = C.c_void_p()
+        small = np.array([[3, 1], [69_999, 2]], dtype=np.uint32).ravel()
+        assert L.ns_segment_upload(ctx, 1, N2, C.c_float(float(np.float32(dl2.astype(np.float64).mean()))), dl2.ctypes.data, small.ctypes.data, small.nbytes, C.byref(seg2)) == 0
+        assert L.ns_segment_build_packed(ctx, seg2) == -1 and b"65536 distinct" in L.ns_last_error(ctx)
+        r2 = np.array([(1, 2, 0, 2.0, 1.0)], dtype=nsbind.TERM_DTYPE)
+        b = nsbind.prepare_raw(ctx, np.array([(0, 1)], dtype=nsbind.QDESC_DTYPE), r2, 10)
+        assert not (b.info().flags & nsbind.NS_INFO_PACKED)
+        b.run(); h, n, f = b.fetch(); b.close()
+        assert int(n[0]) == 2 and int(f[0]) == 2
+        assert L.ns_segment_release(ctx, seg2) == 0
+    finally:
+        L.ns_ctx_destroy(ctx)
 
 
 def test_impact_stream_partial_registration_and_foreign_idf():

@@ -86,10 +86,14 @@ def _run(rng, t0, last, cases, tmp, seconds, max_cases, verbose):
                 if imp:
                     eng.build_impacts()
                 eng.use_impacts(imp)
+                pk = rng.random() < 0.5
+                if pk:
+                    eng.build_packed()
+                eng.use_packed(pk)
                 bad = same(eng.search_batch(qs, k, flags), ora.search_batch(qs, k, flags, threads=8))
                 if bad:
                     return cases, (f"MISMATCH {bad}: index(nseg={nseg}, docs={docs}, vocab={vocab}, seed={seed}) law={law} nq={nq} k={k} "
-                                   f"flags={flags} tune={tune} impacts={imp} queries={qs[:5]}")
+                                   f"flags={flags} tune={tune} impacts={imp} packed={pk} queries={qs[:5]}")
                 cases += 1
                 if verbose and time.time() - last > 30:
                     last = time.time()

@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--laws", default="")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--impacts", action="store_true", help="build the optional impact streams first")
+    ap.add_argument("--packed", action="store_true", help="build the packed posting streams first (driver streams read 4-7 B per posting)")
     ap.add_argument("--segments", type=int, default=1, help="segments of --docs docs each (20 x 1M docs = 1.1 GB of postings: beyond the 256 MiB Infinity Cache)")
     ap.add_argument("--docs", type=int, default=1_000_000)
     ap.add_argument("--qscale", type=float, default=1.0, help="keep only this fraction of every law's queries (every query scans every segment)")
@@ -93,13 +94,15 @@ def main():
     eng.set_tuning(args.variant, 0, args.split)
     if args.impacts:
         eng.build_impacts()
+    if args.packed:
+        eng.build_packed()
     L = laws()
     # every list of ranks 1..4096 scanned by exactly one query: each posting byte is read once per launch
     if args.qscale != 1.0:
         L = {n: (qs[:max(1, int(len(qs) * args.qscale))], k) for n, (qs, k) in L.items()}
     L["scan_once"] = ([T(r) for r in range(1, 4097)], 10)
     names = [n for n in args.laws.split(",") if n] or list(L.keys())
-    print(f"variant={args.variant} split={args.split} impacts={args.impacts} segments={args.segments} docs={args.docs} qscale={args.qscale}")
+    print(f"variant={args.variant} split={args.split} impacts={args.impacts} packed={args.packed} segments={args.segments} docs={args.docs} qscale={args.qscale}")
     print(f"{'law':>14} {'Q':>6} {'post/q':>9} {'items':>7} {'kern_ms':>9} {'ns/post':>8} {'GB/s':>8} {'frac':>6}")
     for n in names:
         qs, k = L[n]
