@@ -151,8 +151,11 @@ int ns_ctx_set_host_threads(ns_ctx* ctx, uint32_t n);
  * foreign windows and doc tiles keep reading the raw stream.  Fails with NS_E_INVAL for a segment with more than
  * 65536 distinct document lengths.  Costs 8 B of HBM per posting (fixed 2 KB stride per block). */
 int ns_segment_build_packed(ns_ctx* ctx, ns_seg* seg);
-/* on = 0: batches prepared from now on ignore packed streams (default: on = 1: used when every segment of the batch has one). */
-int ns_ctx_use_packed(ns_ctx* ctx, int on);
+/* mode 0: batches prepared from now on ignore packed streams.  mode 1 (default): a batch whose segments all have one
+ * reads docIds and tf from the packed blocks and the norms from the per-posting fp32 norm stream (6-7 B per posting, one
+ * memory latency per round).  mode 2: the norms come through the blocks' 16-bit norm index instead (4-5 B per posting, but
+ * the table look-up is a second, dependent access per round). */
+int ns_ctx_use_packed(ns_ctx* ctx, int mode);
 /* on = 0: batches prepared from now on ignore impact streams (default: on = 1). */
 int ns_ctx_use_impacts(ns_ctx* ctx, int on);
 

@@ -163,7 +163,7 @@ struct ns_ctx {
     struct DownSlot { void* p = nullptr; size_t cap = 0; bool busy = false; };
     std::vector<DownSlot> down_slots;
     bool use_impacts = true;   // batches take the impact stream when every list they touch has one (ns_ctx_use_impacts)
-    bool use_packed = true;    // batches read the packed stream when every segment they touch has one (ns_ctx_use_packed)
+    int use_packed = 1;        // 0 off; 1, 2: batches read the packed stream when every segment they touch has one (ns_ctx_use_packed)
     ns_prep* prep = nullptr;   // ns_batch_prepare's host threads and per-thread scratch, kept from batch to batch
     unsigned prep_threads = 0; // 0 = automatic (up to 8); 1 = prepare on the calling thread only (ns_ctx_set_host_threads)
 };
@@ -658,7 +658,8 @@ extern "C" int ns_segment_build_packed(ns_ctx* ctx, ns_seg* seg) {
 
 extern "C" int ns_ctx_use_packed(ns_ctx* ctx, int on) {
     if (!ctx) return NS_E_INVAL;
-    ctx->use_packed = on != 0;
+    if (on < 0 || on > 2) return fail(ctx, NS_E_INVAL, "ns_ctx_use_packed: mode %d (0, 1 or 2)", on);
+    ctx->use_packed = on;
     return NS_OK;
 }
 
@@ -694,7 +695,7 @@ struct ns_batch {
     uint32_t n_terms = 0, n_parts = 0;
     uint64_t postings = 0;
     bool direct = false;   // every query has exactly one work item: the scoring kernel writes final rows
-    bool pk = false;       // every segment of the batch has a packed posting stream: the driver streams read it (ns_segment_build_packed)
+    int pk = 0;            // every segment of the batch has a packed posting stream and the ctx wants it: 1 = packed docIds + tf, norms from the fp32 norm stream; 2 = norms through the 16-bit norm index (ns_ctx_use_packed)
     bool imp = false;      // every list of the batch has an impact stream: the kernels read {docId, score} instead of {docId, tf} + norm
     // device
     DevItem* d_items = nullptr;
@@ -1009,7 +1010,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
     }
     uint64_t bounds_total = 0, postings_total = 0, total_work = 0;
     uint32_t n_dterms = 0, G = 0;
-    bool all_imp = want_imp, all_pk = ctx->use_packed && auto_mode;
+    bool all_imp = want_imp, all_pk = ctx->use_packed != 0 && auto_mode;
     for (unsigned s = 0; s < width; s++) {
         PrepSlice& S = P.slices[s];
         S.term_off = n_dterms; S.bounds_off = bounds_total;
@@ -1158,7 +1159,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
     b->postings = postings_total;
     b->direct = direct;
     b->imp = all_imp && postings_total > 0;
-    b->pk = all_pk && postings_total > 0;
+    b->pk = (all_pk && postings_total > 0) ? ctx->use_packed : 0;
 
     // queries cut into many partial rows: joined by k_merge_wide, one workgroup each
     std::vector<uint32_t> wide_q;
@@ -1337,10 +1338,11 @@ extern "C" int ns_batch_run(ns_batch* b, int run_flags) {
         }
 #define NS_U(CBV, TM, N, PTR)                                                                                      \
         {                                                                                                          \
-            if (b->imp && b->pk) NS_U2(CBV, TM, N, PTR, true, true)                                                \
-            else if (b->imp) NS_U2(CBV, TM, N, PTR, true, false)                                                   \
-            else if (b->pk) NS_U2(CBV, TM, N, PTR, false, true)                                                    \
-            else NS_U2(CBV, TM, N, PTR, false, false)                                                              \
+            if (b->imp && b->pk) NS_U2(CBV, TM, N, PTR, true, 1)          /* scores come with the block: no norms at all */ \
+            else if (b->imp) NS_U2(CBV, TM, N, PTR, true, 0)                                                       \
+            else if (b->pk == 2) NS_U2(CBV, TM, N, PTR, false, 2)                                                  \
+            else if (b->pk == 1) NS_U2(CBV, TM, N, PTR, false, 1)                                                  \
+            else NS_U2(CBV, TM, N, PTR, false, 0)                                                                  \
         }
         const uint32_t n_narrow = b->n_class[0], n_wide = b->n_witems - b->n_class[0];
         (void)grid;

@@ -42,35 +42,46 @@ __device__ unsigned long long g_ns_cnt[16];
 // A driver lookup reads ONE bucket and stops unless the bucket is full and holds no match: with FB/NB <= 0.75
 // a full bucket is a < 1% event, so practically every lookup is a single ds_read_b128 for all 64 lanes.
 // One round of the PACKED posting stream (ns_internal.h kPk*): block `blk` of the segment, decoded into the same
-// registers a raw round fills — docIds, tf as float (or the precomputed score bits when IMP), norms.  Wave-uniform
-// control: the block header comes through scalar loads, the width code selects one of three decode paths.
-template <bool IMP>
+// registers a raw round fills — docIds, tf as float (or the precomputed score bits when IMP), norms.
+//   PKM == 1  norms come from the per-posting fp32 norm stream (DevSeg::pnorm, chunk-major like a block): 6-7 B per posting
+//   PKM == 2  norms come from the block's 16-bit norm index through the table of distinct norms: 4-5 B per posting, but
+//             a dependent gather
+// Every load of the round is issued before the block header (a scalar load) is looked at: only blocks that span >= 65536
+// docs (code 2: tail lists, list boundaries) need two more, dependent loads.
+template <bool IMP, int PKM>
 __device__ __forceinline__ void pk_decode_round(const DevSeg& seg, const uint32_t blk, const int lane, uint32_t (&doc)[4], float (&tf)[4],
                                                 float (&nr)[4], uint32_t (&sbits)[4]) {
     typedef const __attribute__((address_space(1))) uint32_t* gp_u32;
-    const uint2 hd = seg.pk_hdr[blk];                                   // uniform address: scalar load
-    const uint32_t base = __builtin_amdgcn_readfirstlane((int)hd.x);
-    const uint32_t code = __builtin_amdgcn_readfirstlane((int)hd.y);
     const gp_u32 pb = (gp_u32)seg.packed + (size_t)blk * kPkStrideDwords + (uint32_t)lane;
-    if (code == 0u) {
-        const uint32_t d = pb[kPkDoc];
-#pragma unroll
-        for (int c = 0; c < 4; c++) doc[c] = base + ((d >> (8 * c)) & 255u);
-    } else if (code == 1u) {
-        const uint32_t d0 = pb[kPkDoc], d1 = pb[kPkDoc + 64];
-        doc[0] = base + (d0 & 0xFFFFu); doc[1] = base + (d0 >> 16);
-        doc[2] = base + (d1 & 0xFFFFu); doc[3] = base + (d1 >> 16);
-    } else {
-#pragma unroll
-        for (int c = 0; c < 4; c++) doc[c] = pb[kPkDoc + c * 64];
-    }
+    const uint32_t d0 = pb[kPkDoc], d1 = pb[kPkDoc + 64];
+    uint32_t t = 0, na = 0, nb = 0;
     if (IMP) {
         const gp_f32 sc = (gp_f32)seg.pk_scores + (size_t)blk * kPkBlock + (uint32_t)lane;
 #pragma unroll
         for (int c = 0; c < 4; c++) { sbits[c] = __float_as_uint(sc[c * 64]); tf[c] = 0.0f; nr[c] = 0.0f; }
     } else {
-        const uint32_t t = pb[kPkTf], na = pb[kPkNormA], nb = pb[kPkNormB];
-        const gp_f32 ntab = (gp_f32)seg.ntab;
+        t = pb[kPkTf];
+        if (PKM == 2) { na = pb[kPkNormA]; nb = pb[kPkNormB]; }
+        else {
+            const gp_f32 np = (gp_f32)seg.pnorm + (size_t)blk * kPkBlock + (uint32_t)lane;
+#pragma unroll
+            for (int c = 0; c < 4; c++) nr[c] = np[c * 64];
+        }
+    }
+    const uint2 hd = seg.pk_hdr[blk];                                   // uniform address: scalar load
+    const uint32_t base = __builtin_amdgcn_readfirstlane((int)hd.x);
+    const uint32_t code = __builtin_amdgcn_readfirstlane((int)hd.y);
+    if (code == 0u) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) doc[c] = base + ((d0 >> (8 * c)) & 255u);
+    } else if (code == 1u) {
+        doc[0] = base + (d0 & 0xFFFFu); doc[1] = base + (d0 >> 16);
+        doc[2] = base + (d1 & 0xFFFFu); doc[3] = base + (d1 >> 16);
+    } else {
+        doc[0] = d0; doc[1] = d1;
+        doc[2] = pb[kPkDoc + 128]; doc[3] = pb[kPkDoc + 192];
+    }
+    if (!IMP) {
         uint32_t tfi[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) tfi[c] = (t >> (8 * c)) & 255u;
@@ -82,8 +93,11 @@ __device__ __forceinline__ void pk_decode_round(const DevSeg& seg, const uint32_
             for (int c = 0; c < 4; c++)
                 if (tfi[c] == 255u) { const nat_u2 pv = raw[c * 64]; tfi[c] = pv.y; }
         }
-        nr[0] = ntab[na & 0xFFFFu]; nr[1] = ntab[na >> 16];
-        nr[2] = ntab[nb & 0xFFFFu]; nr[3] = ntab[nb >> 16];
+        if (PKM == 2) {
+            const gp_f32 ntab = (gp_f32)seg.ntab;
+            nr[0] = ntab[na & 0xFFFFu]; nr[1] = ntab[na >> 16];
+            nr[2] = ntab[nb & 0xFFFFu]; nr[3] = ntab[nb >> 16];
+        }
 #pragma unroll
         for (int c = 0; c < 4; c++) { tf[c] = (float)tfi[c]; sbits[c] = 0u; }
     }
@@ -96,7 +110,7 @@ __device__ __forceinline__ uint64_t lane_span(uint32_t lo, uint32_t hi) {
     return upto_hi & ~upto_lo;
 }
 
-template <int NB, int FB, bool AND, int CB = 256, bool IMP = false, bool PK = false>
+template <int NB, int FB, bool AND, int CB = 256, bool IMP = false, int PK = 0>
 __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* __restrict__ terms, const DevSeg* __restrict__ segs,
                                             uint32_t* ent, float* vals, uint8_t* mcnt, uint64_t* cand, uint4* tab, uint32_t* aux,
                                             Hit* __restrict__ out_hits, uint32_t* __restrict__ out_nhits,
@@ -485,7 +499,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
                 n = e - a;
                 first_pos = a; last_pos = e - 1u;
                 uint32_t docs_[4];
-                pk_decode_round<IMP>(seg, blk, lane, docs_, tfv, nr, sbits);
+                pk_decode_round<IMP, PK>(seg, blk, lane, docs_, tfv, nr, sbits);
 #pragma unroll
                 for (int j = 0; j < DE; j++) {
                     ps[j].x = docs_[j]; ps[j].y = sbits[j];

@@ -21,7 +21,7 @@ static constexpr uint32_t kTileEmptyBits = 0xFFFFFFFFu;
 //   dword 128 .. 191   norm plane B  chunks 2, 3
 //   dword 192 ..       doc plane     code 0: one dword, byte c = docId - base of chunk c        (block spans < 256 docs)
 //                                    code 1: two dwords (chunks 0|1, chunks 2|3), 16-bit offsets (block spans < 65536 docs)
-//                                    code 2: four dwords, the docIds themselves
+//                                    code 2: four dwords (chunk c at dword 192 + 64 c), the docIds themselves
 // i.e. 4 B (code 0), 5 B (code 1) or 7 B (code 2) per posting are READ; every block owns kPkStrideDwords dwords so that
 // block b sits at b * stride (HBM footprint is not what this format saves; bytes moved per posting are).
 static constexpr uint32_t kPkBlock = 256;

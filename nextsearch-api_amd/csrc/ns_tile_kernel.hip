@@ -344,9 +344,10 @@ __global__ void __launch_bounds__(256) k_tscore(const DevWItem* __restrict__ ite
 // unequal length per workgroup ~12 % of the wave slots sat idle mid-kernel.  One item per workgroup.
 constexpr int kUscoreWavesPerBlock = 1;
 
-// PK: the driver stream reads the packed posting blocks (ns_segment_build_packed) instead of {docId, tf} + norm; foreign
-// windows and doc tiles keep reading the raw stream.
-template <int HK, int FB, bool AND, int CB, int TMAX, bool IMP = false, bool PK = false>
+// PK != 0: the driver stream reads the packed posting blocks (ns_segment_build_packed) instead of {docId, tf}; norms from the
+// fp32 norm stream (PK == 1) or through the blocks' 16-bit norm index (PK == 2).  Foreign windows and doc tiles keep reading
+// the raw stream.
+template <int HK, int FB, bool AND, int CB, int TMAX, bool IMP = false, int PK = 0>
 __global__ void __launch_bounds__(64 * kUscoreWavesPerBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) k_uscore(const DevWItem* __restrict__ items, uint32_t n_items,
                                                 const DevTerm* __restrict__ terms, const DevSeg* __restrict__ segs,
                                                 Hit* __restrict__ out_hits, uint32_t* __restrict__ out_nhits,

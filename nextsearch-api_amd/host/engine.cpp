@@ -203,7 +203,7 @@ bool Engine::build_packed() {
     return true;
 }
 
-void Engine::use_packed(bool on) { std::lock_guard<std::recursive_mutex> lock(mtx_); if (ctx_) ns_ctx_use_packed(ctx_, on ? 1 : 0); }
+void Engine::use_packed(int mode) { std::lock_guard<std::recursive_mutex> lock(mtx_); if (ctx_) ns_ctx_use_packed(ctx_, mode); }
 
 void Engine::use_impacts(bool on) { std::lock_guard<std::recursive_mutex> lock(mtx_); if (ctx_) ns_ctx_use_impacts(ctx_, on ? 1 : 0); }
 

@@ -69,7 +69,7 @@ public:
     // built on the device next to the raw stream (ns_segment_build_packed); the driver streams then read 4-7 B per posting
     // instead of 12.  Same results.
     bool build_packed();
-    void use_packed(bool on);
+    void use_packed(int mode);   // 0 off, 1 packed docIds + tf with the fp32 norm stream (default), 2 norms through the 16-bit index
     std::string search(const std::string& query, int k);        // include/api_engine.hpp:66 (JSON text, dump(2) layout)
     // Search-result cache around search() (src/api_engine.cpp:190-250,:380-385,:539): key "query|K", at most 2600
     // entries, least recently used evicted, a hit returns the stored body plus "from_cache": true.  In memory only:

@@ -332,7 +332,7 @@ extern "C" int nsh_engine_build_packed(nsh_engine* e) { try {
     return 0;
 } NSH_CATCH(e, "nsh_engine_build_packed", -1)
 }
-extern "C" void nsh_engine_use_packed(nsh_engine* e, int on) { try { if (e) e->eng.use_packed(on != 0); } NSH_CATCH_VOID(e, "nsh_engine_use_packed")
+extern "C" void nsh_engine_use_packed(nsh_engine* e, int on) { try { if (e) e->eng.use_packed(on); } NSH_CATCH_VOID(e, "nsh_engine_use_packed")
 }
 extern "C" void nsh_engine_use_impacts(nsh_engine* e, int on) { try { if (e) e->eng.use_impacts(on != 0);  } NSH_CATCH_VOID(e, "nsh_engine_use_impacts")
 }

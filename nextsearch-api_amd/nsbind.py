@@ -441,8 +441,9 @@ class Engine:
         if self._L.nsh_engine_build_packed(self.h) != 0:
             raise RuntimeError(f"build_packed failed: {self.error()}")
 
-    def use_packed(self, on):
-        self._L.nsh_engine_use_packed(self.h, 1 if on else 0)
+    def use_packed(self, mode):
+        """0 off; 1 packed docIds + tf, norms from the fp32 norm stream (default); 2 norms through the 16-bit norm index."""
+        self._L.nsh_engine_use_packed(self.h, int(mode))
 
     def use_impacts(self, on):
         self._L.nsh_engine_use_impacts(self.h, 1 if on else 0)

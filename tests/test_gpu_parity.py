@@ -195,11 +195,13 @@ def test_full_batches_equal_oracle_and_reference_digests(index_factory):
                 assert not bad, f"{cfg}: blocks {bad[:8]} differ from the real reference's tie-invariant digests"
             # the optional streams (packed blocks, impacts, both) must not change a byte either
             eng.build_packed()
-            h2, n2, f2, _ = eng.search_batch(gen(Q), K, flags)
-            assert hits.tobytes() == h2.tobytes() and nhits.tobytes() == n2.tobytes() and found.tobytes() == f2.tobytes(), cfg + " packed"
+            for pk in (1, 2):
+                eng.use_packed(pk)
+                h2, n2, f2, _ = eng.search_batch(gen(Q), K, flags)
+                assert hits.tobytes() == h2.tobytes() and nhits.tobytes() == n2.tobytes() and found.tobytes() == f2.tobytes(), (cfg, "packed", pk)
             if cfg in ("cfg5", "cfg3"):
                 eng.build_impacts()
-                for pk in (True, False):
+                for pk in (1, 0):
                     eng.use_packed(pk)
                     h2, n2, f2, _ = eng.search_batch(gen(Q), K, flags)
                     assert hits.tobytes() == h2.tobytes() and nhits.tobytes() == n2.tobytes() and found.tobytes() == f2.tobytes(), (cfg, "impacts", pk)
@@ -621,9 +623,10 @@ def test_packed_stream_equals_oracle_and_reference_golden(name, golden_index):
         assert not (b.info().flags & nsbind.NS_INFO_PACKED)
         b.close()
         eng.build_packed()
-        for with_impacts in (False, True):
+        for with_impacts, mode in ((False, 1), (False, 2), (True, 1)):
             if with_impacts:
                 eng.build_impacts()
+            eng.use_packed(mode)
             b = eng.prepare(queries, 10)
             fl = b.info().flags
             assert fl & nsbind.NS_INFO_PACKED and bool(fl & nsbind.NS_INFO_IMPACTS) == with_impacts
@@ -646,7 +649,7 @@ def test_packed_stream_equals_oracle_and_reference_golden(name, golden_index):
                 eng.set_tuning(*tune)
                 assert_same(eng.search_batch(queries[:24], 10), ora.search_batch(queries[:24], 10), queries[:24], f"{name} packed split {tune}")
             eng.set_tuning(0, 0, 0)
-        eng.use_packed(False)
+        eng.use_packed(0)
         b = eng.prepare(queries, 10)
         assert not (b.info().flags & nsbind.NS_INFO_PACKED)
         b.close()
@@ -693,8 +696,9 @@ def test_packed_stream_escapes_and_limits():
         refs = np.array(refs, dtype=nsbind.TERM_DTYPE)
         raw = {k: nsbind.search_batch_raw(ctx, qd, refs, k) for k in (10, 100)}
         assert L.ns_segment_build_packed(ctx, seg) == 0, L.ns_last_error(ctx)
-        for split in (0, 200, 1 << 30):
+        for split, mode in ((0, 1), (0, 2), (200, 1), (200, 2), (1 << 30, 2)):
             assert L.ns_set_tuning(ctx, 0, 1 if split else 0, split) == 0
+            assert L.ns_ctx_use_packed(ctx, mode) == 0
             for k in (10, 100):
                 b = nsbind.prepare_raw(ctx, qd, refs, k)
                 assert b.info().flags & nsbind.NS_INFO_PACKED

@@ -86,7 +86,7 @@ def _run(rng, t0, last, cases, tmp, seconds, max_cases, verbose):
                 if imp:
                     eng.build_impacts()
                 eng.use_impacts(imp)
-                pk = rng.random() < 0.5
+                pk = rng.choice([0, 0, 1, 2])
                 if pk:
                     eng.build_packed()
                 eng.use_packed(pk)

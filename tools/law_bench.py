@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--laws", default="")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--impacts", action="store_true", help="build the optional impact streams first")
-    ap.add_argument("--packed", action="store_true", help="build the packed posting streams first (driver streams read 4-7 B per posting)")
+    ap.add_argument("--packed", type=int, default=0, help="build the packed posting streams first and read them in this mode (1: norms from the fp32 stream, 2: through the 16-bit norm index)")
     ap.add_argument("--segments", type=int, default=1, help="segments of --docs docs each (20 x 1M docs = 1.1 GB of postings: beyond the 256 MiB Infinity Cache)")
     ap.add_argument("--docs", type=int, default=1_000_000)
     ap.add_argument("--qscale", type=float, default=1.0, help="keep only this fraction of every law's queries (every query scans every segment)")
@@ -96,6 +96,7 @@ def main():
         eng.build_impacts()
     if args.packed:
         eng.build_packed()
+        eng.use_packed(args.packed)
     L = laws()
     # every list of ranks 1..4096 scanned by exactly one query: each posting byte is read once per launch
     if args.qscale != 1.0:
