@@ -68,9 +68,12 @@ __device__ __forceinline__ void pk_decode_round(const DevSeg& seg, const uint32_
             for (int c = 0; c < 4; c++) nr[c] = np[c * 64];
         }
     }
-    const uint2 hd = seg.pk_hdr[blk];                                   // uniform address: scalar load
-    const uint32_t base = __builtin_amdgcn_readfirstlane((int)hd.x);
-    const uint32_t code = __builtin_amdgcn_readfirstlane((int)hd.y);
+    // the header through the constant address space: a wave-uniform address there is a SCALAR load (s_load_dwordx2), counted
+    // by lgkmcnt — it does not hold up the vector loads above, which a generic (flat) load followed by readfirstlane did
+    typedef const __attribute__((address_space(4))) uint32_t* cp_u32;
+    const cp_u32 hp = (cp_u32)(const void*)(seg.pk_hdr + blk);
+    const uint32_t base = hp[0];
+    const uint32_t code = hp[1];
     if (code == 0u) {
 #pragma unroll
         for (int c = 0; c < 4; c++) doc[c] = base + ((d0 >> (8 * c)) & 255u);
