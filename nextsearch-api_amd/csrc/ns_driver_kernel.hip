@@ -504,12 +504,21 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
                 uint32_t docs_[4];
                 pk_decode_round<IMP, PK>(seg, blk, lane, docs_, tfv, nr, sbits);
 #pragma unroll
-                for (int j = 0; j < DE; j++) {
-                    ps[j].x = docs_[j]; ps[j].y = sbits[j];
-                    const uint32_t c0 = (uint32_t)(j * 64);
-                    const uint64_t vm = lane_span(a > c0 ? a - c0 : 0u, e > c0 ? min(e - c0, 64u) : 0u);
-                    dokm[j] = wballot(ps[j].x <= hi) & vm;
-                    cnt += (uint32_t)__popcll(dokm[j]);
+                for (int j = 0; j < DE; j++) { ps[j].x = docs_[j]; ps[j].y = sbits[j]; }
+                if (n == (uint32_t)(DE * 64)) {   // a whole block (all but the first and the last of a list's range): no lane masks to build
+#pragma unroll
+                    for (int j = 0; j < DE; j++) {
+                        dokm[j] = wballot(ps[j].x <= hi);
+                        cnt += (uint32_t)__popcll(dokm[j]);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < DE; j++) {
+                        const uint32_t c0 = (uint32_t)(j * 64);
+                        const uint64_t vm = lane_span(a > c0 ? a - c0 : 0u, e > c0 ? min(e - c0, 64u) : 0u);
+                        dokm[j] = wballot(ps[j].x <= hi) & vm;
+                        cnt += (uint32_t)__popcll(dokm[j]);
+                    }
                 }
             } else {
                 n = min(remd, (uint32_t)(DE * 64));
@@ -567,11 +576,17 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
             // not when the driver is much denser than the foreign lists: then the lookups are skipped)
             bool any_foreign_here = total > 0;
             if (FB <= 64 && total > 0) {   // only worth testing for the thin-foreign class
-                uint32_t rfirst = 0, rlast = 0;
+                uint32_t rfirst, rlast;
+                if (n == (uint32_t)(DE * 64)) {
+                    rfirst = rdlane(ps[0].x, 0);
+                    rlast = rdlane(ps[DE - 1].x, 63);
+                } else {
+                    rfirst = 0; rlast = 0;
 #pragma unroll
-                for (int j = 0; j < DE; j++) {   // uniform selects
-                    if ((first_pos >> 6) == (uint32_t)j) rfirst = rdlane(ps[j].x, first_pos & 63u);
-                    if ((last_pos >> 6) == (uint32_t)j) rlast = rdlane(ps[j].x, last_pos & 63u);
+                    for (int j = 0; j < DE; j++) {   // uniform selects
+                        if ((first_pos >> 6) == (uint32_t)j) rfirst = rdlane(ps[j].x, first_pos & 63u);
+                        if ((last_pos >> 6) == (uint32_t)j) rlast = rdlane(ps[j].x, last_pos & 63u);
+                    }
                 }
                 bool here = false;
 #pragma unroll
@@ -583,7 +598,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
                 // the term order (foreign terms before it are already in, those after it follow)
 #pragma unroll
                 for (int j = 0; j < DE; j++) {
-                    if (PK ? ((uint32_t)(j * 64) > last_pos || (uint32_t)(j * 64 + 63) < first_pos) : ((uint32_t)(j * 64) >= n)) continue;   // uniform: no posting of this round in the chunk
+                    if (PK ? (dokm[j] == 0ull) : ((uint32_t)(j * 64) >= n)) continue;   // uniform: no posting of this round in the chunk
                     const uint32_t tag = NS_TAG(ps[j].x);
                     uint32_t b = ps[j].x & (uint32_t)(NB - 1);
                     uint4 q = ent4[b];

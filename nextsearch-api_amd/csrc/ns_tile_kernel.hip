@@ -344,9 +344,10 @@ __global__ void __launch_bounds__(256) k_tscore(const DevWItem* __restrict__ ite
 // unequal length per workgroup ~12 % of the wave slots sat idle mid-kernel.  One item per workgroup.
 constexpr int kUscoreWavesPerBlock = 1;
 
-// PK != 0: the driver stream reads the packed posting blocks (ns_segment_build_packed) instead of {docId, tf}; norms from the
-// fp32 norm stream (PK == 1) or through the blocks' 16-bit norm index (PK == 2).  Foreign windows and doc tiles keep reading
-// the raw stream.
+// PK != 0: the driver stream of THIN groups (one list dominates: long runs of whole blocks) reads the packed posting blocks
+// (ns_segment_build_packed) instead of {docId, tf}; norms from the fp32 norm stream (PK == 1) or through the blocks' 16-bit
+// norm index (PK == 2).  General groups (super-batches of ~1.4 blocks: most rounds would be partial blocks, measured 9 %
+// slower), foreign windows and doc tiles keep reading the raw stream.
 template <int HK, int FB, bool AND, int CB, int TMAX, bool IMP = false, int PK = 0>
 __global__ void __launch_bounds__(64 * kUscoreWavesPerBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) k_uscore(const DevWItem* __restrict__ items, uint32_t n_items,
                                                 const DevTerm* __restrict__ terms, const DevSeg* __restrict__ segs,
@@ -374,7 +375,7 @@ __global__ void __launch_bounds__(64 * kUscoreWavesPerBlock) __attribute__((amdg
         tscore_body<2 * HK, AND, CB, IMP>(it, terms, segs, reinterpret_cast<float*>(s_tbl[wave]), s_mcnt[wave], s_cand[wave],
                                  out_hits, out_nhits, out_found, K, lane);
     else
-        dscore_body<HK / 2, FB, AND, CB, IMP, PK>(it, terms, segs, s_tbl[wave], s_vals[wave], s_mcnt[wave], s_cand[wave],
+        dscore_body<HK / 2, FB, AND, CB, IMP, 0>(it, terms, segs, s_tbl[wave], s_vals[wave], s_mcnt[wave], s_cand[wave],
                                  s_tab[wave], s_aux[wave], out_hits, out_nhits, out_found, K, lane);
 }
 

@@ -71,6 +71,8 @@ def laws():
     L["cfg5_seed99_q32768"] = (workloads.cfg5_queries(32768, 99), 10)
     L["cfg5_q4096"] = (workloads.cfg5_queries(4096, 2005), 10)
     L["cfg5_q1024"] = (workloads.cfg5_queries(1024, 2005), 10)
+    L["cfg5_q2048"] = (workloads.cfg5_queries(2048, 2005), 10)
+    L["cfg5_q512"] = (workloads.cfg5_queries(512, 2005), 10)
     L["cfg3_k64"] = (workloads.cfg3_queries(), 64)
     return L
 
@@ -104,7 +106,7 @@ def main():
     L["scan_once"] = ([T(r) for r in range(1, 4097)], 10)
     names = [n for n in args.laws.split(",") if n] or list(L.keys())
     print(f"variant={args.variant} split={args.split} impacts={args.impacts} packed={args.packed} segments={args.segments} docs={args.docs} qscale={args.qscale}")
-    print(f"{'law':>14} {'Q':>6} {'post/q':>9} {'items':>7} {'kern_ms':>9} {'ns/post':>8} {'GB/s':>8} {'frac':>6}")
+    print(f"{'law':>14} {'Q':>6} {'post/q':>9} {'items':>7} {'kern_ms':>9} {'ns/post':>8} {'GB/s':>8} {'frac':>6} {'all_ms':>8}")
     for n in names:
         qs, k = L[n]
         if not qs:
@@ -119,7 +121,7 @@ def main():
         inf = b.info()
         ms = inf.sum_score_kernel_ms / inf.timed_runs
         gbs = inf.algo_bytes / (ms * 1e-3) / 1e9
-        print(f"{n:>14} {len(qs):>6} {inf.postings / len(qs):>9.0f} {inf.n_items:>7} {ms:>9.3f} {ms * 1e6 / inf.postings:>8.4f} {gbs:>8.0f} {gbs / 8000:>6.3f}")
+        print(f"{n:>14} {len(qs):>6} {inf.postings / len(qs):>9.0f} {inf.n_items:>7} {ms:>9.3f} {ms * 1e6 / inf.postings:>8.4f} {gbs:>8.0f} {gbs / 8000:>6.3f} {inf.sum_total_ms / inf.timed_runs:>8.3f}")
         b.close()
     eng.close()
 
