@@ -1025,6 +1025,8 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
     // than ~split_postings units of estimated work (the longest item bounds the batch's tail; launch
     // order is longest-estimated-work first), and (b) so that a small batch still fills the chip.  Partial rows of one query are contiguous; k_merge joins them.
     const uint32_t min_items = ctx->min_items ? ctx->min_items : (uint32_t)std::max(ctx->n_cus, 1) * 24u;
+    bool small_batch = false;
+    int small_mode = 1;
     uint64_t split_postings = ctx->split_postings ? ctx->split_postings
                               : (!auto_mode ? kDefaultSplitPostings : (k <= 32 ? kSplitWorkSmallK : kSplitWorkLargeK));
     if (!ctx->split_postings && auto_mode) {
@@ -1033,6 +1035,11 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
         // below ~16 K units, where an item's fixed cost takes over
         const uint64_t fine = total_work / ((uint64_t)std::max(ctx->n_cus, 1) * 96u);
         split_postings = std::min<uint64_t>(split_postings, std::max<uint64_t>(fine, 16384));
+        // a batch that leaves wave slots idle is bound by its LONGEST item, and a streaming item is a chain of dependent
+        // round trips (one 256-posting round in flight per wave): thin and tile items then get no double share
+        // (measured, profiles/r02: 256 / 512 / 1024 / 2048 queries of the cfg5 law run 36 / 27 / 17 / 6 % faster)
+        small_batch = fine < 16384;
+        small_mode = fine < 6000 ? 2 : 1;
     }
     uint32_t chunks_per_group = 1;
     if (G > 0 && G < min_items) chunks_per_group = std::min<uint32_t>((min_items + G - 1) / G, 1024u);   // one query alone: 1024 ranges are plenty
@@ -1051,7 +1058,8 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                 if (hg.wave) {
                     // thin and tile groups run at a steady rate per posting: fewer, longer items (less per-item set-up,
                     // same balance); groups with dense foreign lists vary more per posting and stay finer
-                    const uint64_t sp_ = (auto_mode && hg.cls != 0) ? split_postings * 2 : split_postings;
+                    uint64_t sp_ = (auto_mode && hg.cls != 0) ? split_postings * 2 : split_postings;
+                    if (small_batch && auto_mode && hg.cls != 0) sp_ = small_mode == 2 ? split_postings / 2 : split_postings;
                     const uint64_t want = std::max<uint64_t>((hg.work + sp_ - 1) / sp_, chunks_per_group);
                     const uint32_t ns = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want, 1), std::min<uint32_t>(sg.n_docs, 4096));
                     // launch-order key = estimated run time of the ITEM: its share of the group's work plus what
@@ -1571,22 +1579,28 @@ extern "C" int ns_invert_forward(ns_ctx* ctx, const uint32_t* doc_term_counts, u
     while (bits < 32 && (n_terms >> bits) != 0) bits++;     // the largest key is n_terms itself
     int passes = (bits + 7) / 8;
 
+    // one block from the ctx pool for all scratch arrays (a build loop inverts segment after segment of similar size;
+    // ten hipMalloc + hipFree per call cost more than the device work)
     uint2 *d_pairs = nullptr, *d_vals[2] = {nullptr, nullptr};
     uint32_t *d_keys[2] = {nullptr, nullptr}, *d_df = nullptr, *d_first = nullptr, *d_hist = nullptr, *d_sums = nullptr;
     uint64_t* d_prefix = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipError_t e = hipSuccess;
     auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-    chk(hipMalloc((void**)&d_pairs, (size_t)n * 8));
-    chk(hipMalloc((void**)&d_vals[0], (size_t)n * 8));
-    chk(hipMalloc((void**)&d_vals[1], (size_t)n * 8));
-    chk(hipMalloc((void**)&d_keys[0], (size_t)n * 4));
-    chk(hipMalloc((void**)&d_keys[1], (size_t)n * 4));
-    chk(hipMalloc((void**)&d_df, (size_t)std::max<uint32_t>(n_terms, 1) * 4));
-    chk(hipMalloc((void**)&d_first, (size_t)std::max<uint32_t>(n_terms, 1) * 4));
-    chk(hipMalloc((void**)&d_hist, m * 4));
-    chk(hipMalloc((void**)&d_sums, (size_t)scan_blocks * 4));
-    chk(hipMalloc((void**)&d_prefix, prefix.size() * 8));
+    size_t off = 0;
+    auto place = [&](size_t bytes) { const size_t o = off; off = (off + std::max<size_t>(bytes, 1) + 255) & ~(size_t)255; return o; };
+    const size_t nt1 = (size_t)std::max<uint32_t>(n_terms, 1);
+    const size_t o_pairs = place((size_t)n * 8), o_v0 = place((size_t)n * 8), o_v1 = place((size_t)n * 8), o_k0 = place((size_t)n * 4), o_k1 = place((size_t)n * 4);
+    const size_t o_df = place(nt1 * 4), o_first = place(nt1 * 4), o_hist = place(m * 4), o_sums = place((size_t)scan_blocks * 4), o_prefix = place(prefix.size() * 8);
+    const size_t block_bytes = off;
+    char* blk = nullptr;
+    chk(pool_alloc(ctx, (void**)&blk, block_bytes));
+    if (e == hipSuccess) {
+        d_pairs = (uint2*)(blk + o_pairs); d_vals[0] = (uint2*)(blk + o_v0); d_vals[1] = (uint2*)(blk + o_v1);
+        d_keys[0] = (uint32_t*)(blk + o_k0); d_keys[1] = (uint32_t*)(blk + o_k1);
+        d_df = (uint32_t*)(blk + o_df); d_first = (uint32_t*)(blk + o_first); d_hist = (uint32_t*)(blk + o_hist); d_sums = (uint32_t*)(blk + o_sums);
+        d_prefix = (uint64_t*)(blk + o_prefix);
+    }
     chk(hipEventCreate(&ev0));
     chk(hipEventCreate(&ev1));
     if (e == hipSuccess) {
@@ -1635,8 +1649,7 @@ extern "C" int ns_invert_forward(ns_ctx* ctx, const uint32_t* doc_term_counts, u
             if (e == hipSuccess && hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess && device_ms_out) *device_ms_out = ms;
         }
     }
-    (void)hipFree(d_pairs); (void)hipFree(d_vals[0]); (void)hipFree(d_vals[1]); (void)hipFree(d_keys[0]); (void)hipFree(d_keys[1]);
-    (void)hipFree(d_df); (void)hipFree(d_first); (void)hipFree(d_hist); (void)hipFree(d_sums); (void)hipFree(d_prefix);
+    if (blk) { (void)hipStreamSynchronize(st); pool_free(ctx, blk, block_bytes); }   // nothing in flight uses the block any more
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? NS_E_NOMEM : NS_E_HIP, "ns_invert_forward: %s", hipGetErrorString(e));
@@ -1737,14 +1750,18 @@ extern "C" int ns_sem_topk(ns_ctx* ctx, ns_sem* sem, const float* qvecs, uint32_
     hipError_t e = hipSuccess;
     auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
     const size_t n_pad = (size_t)n_groups * kSemB;
-    chk(hipMalloc((void**)&d_q, qpad.size() * 4));
-    chk(hipMalloc((void**)&d_sims, (size_t)kSemB * rp * 4));
-    chk(hipMalloc((void**)&d_cand, (size_t)kSemB * n_cand * 8));
-    chk(hipMalloc((void**)&d_goff, goff.size() * 4));
-    chk(hipMalloc((void**)&d_grows, grows.size() * 4));
-    chk(hipMalloc((void**)&d_orows, n_pad * topk * 4));
-    chk(hipMalloc((void**)&d_osims, n_pad * topk * 4));
-    chk(hipMalloc((void**)&d_ocnt, n_pad * 4));
+    // one block from the ctx pool for all scratch arrays (every search of a serving loop expands its query)
+    size_t off = 0;
+    auto place = [&](size_t bytes) { const size_t o = off; off = (off + std::max<size_t>(bytes, 1) + 255) & ~(size_t)255; return o; };
+    const size_t o_q = place(qpad.size() * 4), o_sims = place((size_t)kSemB * rp * 4), o_cand = place((size_t)kSemB * n_cand * 8), o_goff = place(goff.size() * 4),
+                 o_grows = place(grows.size() * 4), o_orows = place(n_pad * topk * 4), o_osims = place(n_pad * topk * 4), o_ocnt = place(n_pad * 4);
+    const size_t block_bytes = off;
+    char* blk = nullptr;
+    chk(pool_alloc(ctx, (void**)&blk, block_bytes));
+    if (e == hipSuccess) {
+        d_q = (float*)(blk + o_q); d_sims = (float*)(blk + o_sims); d_cand = (uint64_t*)(blk + o_cand); d_goff = (uint32_t*)(blk + o_goff);
+        d_grows = (uint32_t*)(blk + o_grows); d_orows = (uint32_t*)(blk + o_orows); d_osims = (float*)(blk + o_osims); d_ocnt = (uint32_t*)(blk + o_ocnt);
+    }
     chk(hipEventCreate(&ev0));
     chk(hipEventCreate(&ev1));
     if (e == hipSuccess) {
@@ -1766,8 +1783,7 @@ extern "C" int ns_sem_topk(ns_ctx* ctx, ns_sem* sem, const float* qvecs, uint32_
         float ms = 0.0f;
         if (e == hipSuccess && device_ms_out && hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) *device_ms_out = ms;
     }
-    (void)hipFree(d_q); (void)hipFree(d_sims); (void)hipFree(d_cand); (void)hipFree(d_goff); (void)hipFree(d_grows);
-    (void)hipFree(d_orows); (void)hipFree(d_osims); (void)hipFree(d_ocnt);
+    if (blk) { (void)hipStreamSynchronize(st); pool_free(ctx, blk, block_bytes); }
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? NS_E_NOMEM : NS_E_HIP, "ns_sem_topk: %s", hipGetErrorString(e));
