@@ -239,26 +239,31 @@ def main():
             assert last[0].tobytes() == k_hits.tobytes() and last[1].tobytes() == k_nhits.tobytes() and last[2].tobytes() == k_found.tobytes(), \
                 "pipelined results differ from the kernel leg's"
         else:
-            # every rank: prepare(own shard) -> kernels into ITS packed block -> ONE all-gather of the blocks (asynchronous,
-            # ordered behind the batch's stream); up to `depth` steps in flight
+            # every rank: prepare(own shard) -> kernels into ITS packed block -> ONE all-gather of the blocks; up to `depth`
+            # steps in flight (the host only waits for the step that left the pipeline)
             nbytes, off_n, off_f = shard.packed_layout(per, K)
             blocks = [shard.alloc_packed(per, K, "cuda") for _ in range(depth)]
             gathered = [torch.empty(n_gpus * nbytes, dtype=torch.uint8, device="cuda") for _ in range(depth)]
             torch.cuda.synchronize()
+
+            # batches alternate between two torch streams (the ctx works on whichever it is given): the collective of
+            # step i — enqueued behind stream i's kernels, as any torch collective is ordered after the current stream —
+            # then overlaps the kernels of step i+1 on the other stream
+            streams = [torch.cuda.Stream() for _ in range(1 if args.no_overlap else 2)]
 
             def run_steps(n):
                 flight = deque()
                 for i in range(n):
                     if len(flight) >= depth:
                         flight.popleft()()
+                    st = streams[i % len(streams)]
+                    L.ns_ctx_set_stream(eng.ctx, st.cuda_stream)
                     b = nsbind.prepare_raw(eng.ctx, qd, refs, K, flags)
                     blk = blocks[i % depth]
                     b.bind_outputs(blk.data_ptr(), blk.data_ptr() + off_n, blk.data_ptr() + off_f)
                     b.run(timed=False)
-                    st = torch.cuda.ExternalStream(b.stream)
                     with torch.cuda.stream(st):
-                        work = shard.gather_packed(blk, gathered[i % depth], async_op=True)
-                        work.wait()                      # the batch's stream waits for the collective (no host block)
+                        shard.gather_packed(blk, gathered[i % depth])   # ONE collective per step
                         ev = torch.cuda.Event()
                         ev.record(st)
 
@@ -268,6 +273,7 @@ def main():
                     flight.append(retire)
                 while flight:
                     flight.popleft()()
+                L.ns_ctx_set_stream(eng.ctx, None)
 
             run_steps(args.warmup)
             dist.barrier()
