@@ -1025,8 +1025,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
     // than ~split_postings units of estimated work (the longest item bounds the batch's tail; launch
     // order is longest-estimated-work first), and (b) so that a small batch still fills the chip.  Partial rows of one query are contiguous; k_merge joins them.
     const uint32_t min_items = ctx->min_items ? ctx->min_items : (uint32_t)std::max(ctx->n_cus, 1) * 24u;
-    bool small_batch = false;
-    int small_mode = 1;
+    int small_mode = 0;   // thin / tile items: 0 = double share, 1 = plain share, 2 = half share (see below)
     uint64_t split_postings = ctx->split_postings ? ctx->split_postings
                               : (!auto_mode ? kDefaultSplitPostings : (k <= 32 ? kSplitWorkSmallK : kSplitWorkLargeK));
     if (!ctx->split_postings && auto_mode) {
@@ -1035,11 +1034,13 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
         // below ~16 K units, where an item's fixed cost takes over
         const uint64_t fine = total_work / ((uint64_t)std::max(ctx->n_cus, 1) * 96u);
         split_postings = std::min<uint64_t>(split_postings, std::max<uint64_t>(fine, 16384));
-        // a batch that leaves wave slots idle is bound by its LONGEST item, and a streaming item is a chain of dependent
-        // round trips (one 256-posting round in flight per wave): thin and tile items then get no double share
-        // (measured, profiles/r02: 256 / 512 / 1024 / 2048 queries of the cfg5 law run 36 / 27 / 17 / 6 % faster)
-        small_batch = fine < 16384;
-        small_mode = fine < 6000 ? 2 : 1;
+        // A batch that leaves wave slots idle is bound by its LONGEST item, and a streaming item is a chain of dependent
+        // round trips (one 256-posting round in flight per wave).  When the double share of a thin or tile item would
+        // exceed what a wave slot gets on average, those items lose it; when even a plain share does, they are halved
+        // (profiles/r02/small_batch_split_modes.txt: 256 / 512 / 1024 queries of the cfg5 law run 36 / 27 / 14 % faster;
+        // batches that fill the chip — all thin groups of cfg5 alone, 4096 single-term queries — are left as they were).
+        const uint64_t per_slot = total_work / ((uint64_t)std::max(ctx->n_cus, 1) * 24u);
+        small_mode = per_slot >= 2 * split_postings ? 0 : (per_slot >= split_postings ? 1 : 2);
     }
     uint32_t chunks_per_group = 1;
     if (G > 0 && G < min_items) chunks_per_group = std::min<uint32_t>((min_items + G - 1) / G, 1024u);   // one query alone: 1024 ranges are plenty
@@ -1059,7 +1060,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                     // thin and tile groups run at a steady rate per posting: fewer, longer items (less per-item set-up,
                     // same balance); groups with dense foreign lists vary more per posting and stay finer
                     uint64_t sp_ = (auto_mode && hg.cls != 0) ? split_postings * 2 : split_postings;
-                    if (small_batch && auto_mode && hg.cls != 0) sp_ = small_mode == 2 ? split_postings / 2 : split_postings;
+                    if (auto_mode && hg.cls != 0 && small_mode) sp_ = small_mode == 2 ? split_postings / 2 : split_postings;
                     const uint64_t want = std::max<uint64_t>((hg.work + sp_ - 1) / sp_, chunks_per_group);
                     const uint32_t ns = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want, 1), std::min<uint32_t>(sg.n_docs, 4096));
                     // launch-order key = estimated run time of the ITEM: its share of the group's work plus what
