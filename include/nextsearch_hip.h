@@ -132,8 +132,10 @@ int ns_segment_build_impacts(ns_ctx* ctx, ns_seg* seg, const uint64_t* byte_off,
                              const float* idfs, uint32_t n_lists);
 /* on != 0: batches prepared from now on alternate between the ctx's stream and a second one, so that the first work
  * items of batch i+1 fill the wave slots the draining tail of batch i leaves idle (matters most for small batches:
- * a 2048-query shard of a strong-scaled batch).  Only with the ctx's own stream (ignored after ns_ctx_set_stream with
- * a caller's stream).  A batch's upload, kernels and result copy all stay on the one stream it was prepared on. */
+ * a 2048-query shard of a strong-scaled batch).  The alternation applies to the ctx's own stream (a caller who passes
+ * streams with ns_ctx_set_stream alternates them itself).  A batch's upload, kernels and result copy all stay on the one
+ * stream it was prepared on; with overlap on, the descriptor upload is pulled by a kernel instead of the DMA engine (copies
+ * of all streams share one in-order DMA queue, which would chain batch i+1's upload to batch i's result copy). */
 int ns_ctx_set_overlap(ns_ctx* ctx, int on);
 /* Host threads ns_batch_prepare may use for a large batch (regrouping the term refs, cutting work items, writing the
  * descriptors): 0 = automatic (up to 8, one per ~1500 queries), 1 = the calling thread only.  The prepared batch — every
@@ -190,6 +192,9 @@ int  ns_batch_run(ns_batch* b, int run_flags);
 /* The hipStream_t this batch's work is enqueued on (the ctx's stream, or its second one under ns_ctx_set_overlap) —
  * for callers that order their own device work behind the batch (bench.py: the RCCL all-gather of a rank's results). */
 void* ns_batch_stream(ns_batch* b);
+/* Diagnostic for pipelined loops: device time from the end of `prev`'s last kernel to the start of `next`'s first one (both
+ * run with NS_RUN_TIMED, both still alive); negative when they overlapped.  NS_E_STATE while `next` has not started. */
+int  ns_batch_gap_ms(ns_batch* prev, ns_batch* next, float* ms);
 int  ns_batch_sync(ns_batch* b);
 int  ns_batch_fetch(ns_batch* b, ns_hit* hits_out, uint32_t* nhits_out, uint64_t* found_out);
 int  ns_batch_get_info(ns_batch* b, ns_batch_info* info);

@@ -1279,7 +1279,11 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
         if (staged) {
             // a small upload is pulled by a kernel (the pinned buffer is device-addressable): a DMA-engine copy
             // followed by a kernel costs ~11 us of cross-engine hand-over, more than the copy itself
-            if (up_bytes <= kPullUploadBytes)
+            // ... and with batches alternating between two streams (ns_ctx_set_overlap) EVERY upload is pulled: copies of all
+            // streams go through one in-order DMA queue, where batch i+1's upload would sit behind batch i's result copy
+            // — i.e. wait for batch i's kernels — and batch i+1's kernels with it (measured: 0.12 ms between consecutive
+            // batches on two streams, as much as on one)
+            if (up_bytes <= kPullUploadBytes || ctx->overlap)
                 hipLaunchKernelGGL(k_pull, dim3((uint32_t)((up_bytes / 16 + 255) / 256)), dim3(256), 0, b->st,
                                    (uint4*)base, (const uint4*)hb, (uint32_t)(up_bytes / 16));
             else
@@ -1444,6 +1448,18 @@ extern "C" int ns_batch_run(ns_batch* b, int run_flags) {
 }
 
 extern "C" void* ns_batch_stream(ns_batch* b) { return b ? (void*)b->st : nullptr; }
+
+// Diagnostic: device time between the END of `prev`'s last timed run (after its last kernel) and the START of `next`'s
+// (before its first kernel) — the idle or overlapped time between two batches of a pipelined loop.  Both must have been
+// run with NS_RUN_TIMED and must still exist; NS_E_STATE while `next` has not started yet.
+extern "C" int ns_batch_gap_ms(ns_batch* prev, ns_batch* next, float* ms) {
+    if (!prev || !next || !ms) return NS_E_INVAL;
+    if (prev->ev_pool.size() < 4 || next->ev_pool.size() < 4) return fail(next->ctx, NS_E_STATE, "ns_batch_gap_ms: both batches need a timed run");
+    const hipError_t e = hipEventElapsedTime(ms, prev->ev_pool[3], next->ev_pool[0]);
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return NS_E_STATE; }
+    if (e != hipSuccess) return fail(next->ctx, NS_E_HIP, "ns_batch_gap_ms: %s", hipGetErrorString(e));
+    return NS_OK;
+}
 
 
 // reads the HIP-event timings of the runs since the last call (all of them lie before the point the caller has waited for)

@@ -54,7 +54,7 @@ assert QDESC_DTYPE.itemsize == C.sizeof(NsQueryDesc) == 8
 HIP_SYMBOLS = [
     "ns_ctx_create", "ns_ctx_destroy", "ns_ctx_set_stream", "ns_last_error", "ns_device_name",
     "ns_segment_upload", "ns_segment_release", "ns_segment_upload_begin", "ns_segment_upload_append", "ns_segment_upload_end", "ns_search_batch", "ns_batch_prepare",
-    "ns_batch_bind_outputs", "ns_batch_run", "ns_batch_stream", "ns_batch_sync", "ns_batch_fetch", "ns_batch_get_info",
+    "ns_batch_bind_outputs", "ns_batch_run", "ns_batch_stream", "ns_batch_gap_ms", "ns_batch_sync", "ns_batch_fetch", "ns_batch_get_info",
     "ns_batch_destroy", "ns_set_tuning", "ns_segment_build_impacts", "ns_ctx_use_impacts", "ns_ctx_set_host_threads", "ns_ctx_set_overlap", "ns_segment_build_packed", "ns_ctx_use_packed",
     "ns_invert_forward", "ns_merge_rank_rows", "ns_sem_upload", "ns_sem_release", "ns_sem_topk",
 ]
@@ -108,6 +108,7 @@ def hip_lib():
         L.ns_batch_prepare.argtypes = [vp, vp, vp, u32, u32, u32, C.POINTER(vp)]
         L.ns_batch_bind_outputs.argtypes = [vp, vp, vp, vp]
         L.ns_batch_run.argtypes = [vp, i32]
+        L.ns_batch_gap_ms.argtypes = [vp, vp, C.POINTER(C.c_float)]
         L.ns_batch_stream.argtypes = [vp]
         L.ns_batch_stream.restype = vp
         L.ns_batch_sync.argtypes = [vp]

@@ -40,6 +40,28 @@ for threads in (1, 2, 4, 8, 0):
     dt = time.perf_counter() - t0
     print(f"host threads {threads or 'auto'}: ns_batch_prepare alone {1e3 * min(t_prep):.2f} ms (best of 5) | pipelined host->host {1e3 * dt / n:.2f} ms per batch = {Q * n / dt:.0f} q/s")
 L.ns_ctx_set_host_threads(eng.ctx, 0)
+# where a pipelined step's time goes: the kernels' own HIP-event times inside the pipelined loop (one stream, then two)
+import ctypes as C  # noqa: E402
+from collections import deque  # noqa: E402
+for overlap in (0, 1):
+    L.ns_ctx_set_overlap(eng.ctx, overlap)
+    ks, ts, gaps = [], [], []
+    flight = deque()
+    t0 = time.perf_counter()
+    for i in range(24):
+        b = nsbind.prepare_raw(eng.ctx, qd, refs, 10); b.run(timed=True, fetch=True); flight.append(b)
+        if len(flight) >= 4:                      # keep the retired batch's successor alive: the gap needs both
+            old = flight.popleft(); old.fetch_into(*out[0]); inf = old.info()
+            g = C.c_float()
+            if L.ns_batch_gap_ms(old.h, flight[0].h, C.byref(g)) == 0:
+                gaps.append(g.value)
+            ks.append(inf.last_score_kernel_ms); ts.append(inf.last_total_ms); old.close()
+    while flight:
+        old = flight.popleft(); old.fetch_into(*out[0]); old.close()
+    dt = time.perf_counter() - t0
+    print(f"pipelined, 4 in flight, overlap {overlap}: {1e3 * dt / 24:.3f} ms per batch; scoring kernel by HIP events {sum(ks[4:]) / len(ks[4:]):.3f} ms, all kernels {sum(ts[4:]) / len(ts[4:]):.3f} ms, "
+          f"device gap between consecutive batches {sum(gaps[4:]) / max(len(gaps[4:]), 1):.3f} ms (min {min(gaps[4:]):.3f}, max {max(gaps[4:]):.3f})")
+L.ns_ctx_set_overlap(eng.ctx, 0)
 # batches alternating between two streams (ns_ctx_set_overlap): the tail of batch i overlaps the head of batch i+1
 for nq in (16384, 4096, 2048, 1024, 256):
     qd_s, refs_s, _ = eng.build_refs(qs[:nq])
