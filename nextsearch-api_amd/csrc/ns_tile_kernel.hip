@@ -355,20 +355,11 @@ __global__ void __launch_bounds__(64 * kUscoreWavesPerBlock) __attribute__((amdg
                                                 uint64_t* __restrict__ out_found, uint32_t K) {
     constexpr int WPB = kUscoreWavesPerBlock;
     __shared__ __attribute__((aligned(16))) uint32_t s_tbl[WPB][2 * HK];                 // HK/2 buckets of 4 entries, or one 2*HK-doc tile
-#ifdef NS_TILE_ONLY   /* experiment: LDS as a tile-only kernel would have it (the driver body must not run) */
-    __shared__ __attribute__((aligned(16))) float s_vals[WPB][4];
-#else
     __shared__ __attribute__((aligned(16))) float s_vals[WPB][FB];                       // driver body: one accumulator per foreign posting
-#endif
     __shared__ __attribute__((aligned(16))) uint8_t s_mcnt[WPB][AND ? 2 * HK : 16];
     __shared__ uint64_t s_cand[WPB][CB];
-#ifdef NS_TILE_ONLY
-    __shared__ __attribute__((aligned(16))) uint4 s_tab[WPB][1];
-    __shared__ uint32_t s_aux[WPB][1];
-#else
     __shared__ __attribute__((aligned(16))) uint4 s_tab[WPB][TMAX];
     __shared__ uint32_t s_aux[WPB][TMAX];
-#endif
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: the item is fetched with scalar loads
     const int lane = threadIdx.x & 63;
     const uint32_t item_idx = blockIdx.x * WPB + wave;
