@@ -1817,4 +1817,12 @@ extern "C" int ns_debug_counters(unsigned long long* out, int reset) {
     if (reset) { std::memset(h, 0, sizeof(h)); if (hipMemcpyToSymbol(HIP_SYMBOL(ns::g_ns_cnt), h, sizeof(h)) != hipSuccess) return -1; }
     return 0;
 }
+extern "C" int ns_debug_tile_counters(unsigned long long* out, int reset) {
+    unsigned long long h[8];
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(ns::g_ns_tcnt), sizeof(h)) != hipSuccess) return -1;
+    if (out) std::memcpy(out, h, sizeof(h));
+    if (reset) { std::memset(h, 0, sizeof(h)); if (hipMemcpyToSymbol(HIP_SYMBOL(ns::g_ns_tcnt), h, sizeof(h)) != hipSuccess) return -1; }
+    return 0;
+}
 #endif

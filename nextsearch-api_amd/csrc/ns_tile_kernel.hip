@@ -22,6 +22,10 @@
 
 namespace ns {
 
+#ifdef NS_COUNT
+__device__ unsigned long long g_ns_tcnt[8];   // diagnostic build: event counts of the doc-tile body (tools/dbg/count_run.py)
+#endif
+
 template <int TD, bool AND, int CB = 256, bool IMP = false>
 __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* __restrict__ terms, const DevSeg* __restrict__ segs,
                                             float* vals, uint8_t* mcnt, uint64_t* cand,
@@ -74,6 +78,13 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
     uint32_t ncand = 0;
     uint32_t nsorted = 0;   // leading candidates already in descending order (left by the last shrink)
     uint32_t found_s = 0;   // wave-uniform count (popcounts of ballots)
+#ifdef NS_COUNT
+    unsigned long long tc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define NS_TCNT(i, v) tc_[(i)] += (unsigned long long)(v)
+    NS_TCNT(0, 1);
+#else
+#define NS_TCNT(i, v)
+#endif
     wave_sync();
 
     // One round = up to E*64 postings of one term, loaded with a scalar base + a fixed lane offset (lanes
@@ -118,6 +129,8 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
     NS_TILE_HEADER();
     while (!done) {
         const uint32_t tile_lo = lo, tile_hi = hi;
+        NS_TCNT(1, 1);                               // tiles
+        NS_TCNT(2, __popcll(act));                   // (term, tile) visits
         // ---- the terms that have postings in this tile, in query order (the fp32 accumulation order) ----
         while (act != 0ull) {
             const uint32_t t = (uint32_t)__builtin_ctzll(act);
@@ -140,6 +153,8 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
                     n = NS_ROUND_SIZE(remd, want);
                     NS_ISSUE(ps, nr, s_cur, n);
                 }
+                NS_TCNT(3, 1);                       // rounds
+                NS_TCNT(4, (n + 63) / 64);           // chunks loaded
                 const bool expect_more = want > n;
                 want = expect_more ? (want - n) : 64u;
                 // ---- prefetch the round expected next ----
@@ -207,6 +222,7 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
                         if (AND) mcnt[slot[j]] = (uint8_t)(mcnt[slot[j]] + 1);
                     }
                 }
+                NS_TCNT(5, cnt);                     // postings taken
                 s_cur += cnt;
                 if (cnt < n) {   // reached the end of the tile: the first posting not taken is the term's next doc
                     // select the chunk with two uniform v_cndmask levels, then ONE readlane
@@ -313,6 +329,12 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
         out_nhits[it.out_slot] = n;
         out_found[it.out_slot] = (uint64_t)found_s;
     }
+#ifdef NS_COUNT
+    NS_TCNT(6, T);
+    if (lane == 0)
+        for (int i = 0; i < 8; i++) if (tc_[i]) atomicAdd(&g_ns_tcnt[i], tc_[i]);
+#endif
+#undef NS_TCNT
 }
 
 template <int TD, bool AND>

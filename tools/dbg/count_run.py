@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.join(ROOT, "nextsearch-api_amd")); sys.path.insert(0,
 import nsbind, law_bench
 L = nsbind.hip_lib()
 L.ns_debug_counters.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+L.ns_debug_tile_counters.argtypes = [C.POINTER(C.c_uint64), C.c_int]
 tmp = tempfile.TemporaryDirectory(); idx = os.path.join(tmp.name, "i")
 nsbind.gen_index(idx, 1, 1_000_000, 65536, 1337, False)
 eng = nsbind.Engine(idx, 0)
@@ -21,9 +22,10 @@ for n in (sys.argv[1] if len(sys.argv) > 1 else "cfg5_gen").split(","):
     qs, k = laws[n]
     b = eng.prepare(qs, k)
     out = (C.c_uint64 * 16)()
-    L.ns_debug_counters(out, 1)
+    tout = (C.c_uint64 * 8)()
+    L.ns_debug_counters(out, 1); L.ns_debug_tile_counters(tout, 1)
     b.run(True); b.sync()
-    L.ns_debug_counters(out, 1)
+    L.ns_debug_counters(out, 1); L.ns_debug_tile_counters(tout, 1)
     inf = b.info()
     sb = max(out[1], 1)
     print(f"{n}: postings {inf.postings}, kernel {inf.last_score_kernel_ms:.3f} ms")
@@ -32,4 +34,8 @@ for n in (sys.argv[1] if len(sys.argv) > 1 else "cfg5_gen").split(","):
     print(f"    foreign window utilisation {out[4] / max(out[3], 1):.3f}; lanes used in foreign chunks {out[4] / max(out[5] * 64, 1):.3f}; "
           f"driver round utilisation {out[9] / max(out[8] * 256, 1):.3f}; lanes used in driver chunks {out[9] / max(out[12] * 64, 1):.3f}; "
           f"foreign share of consumed postings {out[4] / max(out[4] + out[9], 1):.3f}")
+    if tout[0]:
+        t = max(tout[1], 1)
+        print(f"    doc-tile body: items {tout[0]}, tiles {tout[1]}, (term, tile) visits {tout[2]} ({tout[2] / t:.2f} per tile), rounds {tout[3]} ({tout[3] / max(tout[2], 1):.2f} per visit), "
+              f"chunks loaded {tout[4]} ({tout[4] / t:.2f} per tile), postings taken {tout[5]} ({tout[5] / t:.1f} per tile; lanes used {tout[5] / max(tout[4] * 64, 1):.3f}), terms per item {tout[6] / tout[0]:.2f}")
     b.close()
