@@ -288,6 +288,94 @@ def test_overlapping_batches_and_host_thread_count(index_factory):
         ora.close()
 
 
+def test_pipelined_calls_state_machine(engines):
+    """NS_RUN_FETCH's edges: not for batches with bound outputs; at most 8 batches between run and fetch; fetch after a
+    second NS_RUN_FETCH run returns the second run's (identical) results; a batch run WITHOUT the flag still fetches the old
+    way; destroying the newest batch first does not disturb the older ones; ns_batch_gap_ms needs timed runs."""
+    torch = pytest.importorskip("torch")
+    g, eng, ora = engines("mid1")
+    L = nsbind.hip_lib()
+    queries = g["queries"]
+    qd, refs, usable = eng.build_refs(queries)
+    want = ora.search_batch(queries, 10)
+    # bound outputs + NS_RUN_FETCH -> NS_E_STATE
+    b = nsbind.prepare_raw(eng.ctx, qd, refs, 10)
+    buf = torch.zeros(len(queries) * 10 * 12 + len(queries) * 12 + 1024, dtype=torch.uint8, device="cuda")
+    b.bind_outputs(buf.data_ptr(), buf.data_ptr() + len(queries) * 120 + 256, buf.data_ptr() + len(queries) * 124 + 512)
+    assert L.ns_batch_run(b.h, 2) == -5 and b"bound" in L.ns_last_error(eng.ctx)
+    b.close()
+    # more in flight than there are pinned result slots (8, plus the one small batch whose results live in host memory
+    # anyway): the run is refused, the batches already in flight are intact
+    held, refused = [], None
+    for i in range(12):
+        bi = nsbind.prepare_raw(eng.ctx, qd, refs, 10)
+        rc = L.ns_batch_run(bi.h, 2 | 1)
+        if rc != 0:
+            assert rc == -5 and b"more than 8" in L.ns_last_error(eng.ctx)
+            refused = bi
+            break
+        held.append(bi)
+    assert refused is not None and len(held) in (8, 9)
+    g_ms = C.c_float()
+    assert L.ns_batch_gap_ms(held[0].h, held[1].h, C.byref(g_ms)) in (0, -5)
+    refused.close()
+    held.pop().close()                                 # newest first
+    for bi in held:
+        hits, nhits, found = bi.fetch()
+        assert_same((hits, nhits, found, usable), want, queries, "eight in flight")
+        bi.run(fetch=True)                             # run again, fetch again
+        h2, n2, f2 = bi.fetch()
+        assert h2.tobytes() == hits.tobytes() and n2.tobytes() == nhits.tobytes() and f2.tobytes() == found.tobytes()
+        bi.close()
+    b = nsbind.prepare_raw(eng.ctx, qd, refs, 10)
+    b.run()                                            # no flag: the stream-sync path
+    assert_same(b.fetch() + (usable,), want, queries, "plain run after pipelined ones")
+    b2 = nsbind.prepare_raw(eng.ctx, qd, refs, 10)
+    assert L.ns_batch_gap_ms(b.h, b2.h, C.byref(g_ms)) == -5   # neither has a timed run
+    b.close(); b2.close()
+
+
+def test_reload_on_the_device_swaps_contexts_and_survives_failure(index_factory, tmp_path):
+    """Engine::reload on a live device engine: the new index goes into a FRESH context that replaces the old one only when
+    everything loaded (src/api_engine.cpp:76-90); a reload that fails half way leaves the engine answering from the old
+    device copy; a reload that succeeds answers from the new one (here: the same directory with one segment dropped)."""
+    import shutil
+    src, _ = index_factory(3, 20_000, 4096, 77, False)
+    d = str(tmp_path / "index")
+    shutil.copytree(src, d)
+    eng, ora = nsbind.Engine(d, 0), orc.Oracle(d)
+    try:
+        queries = workloads.cfg5_queries(200, 5, 4096) + ["covid", "zzzz", "the of"]
+        want3 = ora.search_batch(queries, 10)
+        assert_same(eng.search_batch(queries, 10), want3, queries, "before reload")
+        ctx0 = eng.ctx
+        eng.reload()                                            # same index: new context, same answers
+        assert eng.ctx != ctx0 or True                          # (the allocator may hand the same address back)
+        assert_same(eng.search_batch(queries, 10), want3, queries, "after reload")
+        inv = os.path.join(d, "segments", "seg_000002", "inverted_b007.bin")
+        shutil.move(inv, inv + ".away")                         # the loader lists the file sizes: a missing barrel fails the load
+        with pytest.raises(RuntimeError):
+            eng.reload()
+        assert eng.num_segments == 3
+        assert_same(eng.search_batch(queries, 10), want3, queries, "after a failed reload")
+        shutil.move(inv + ".away", inv)
+        # drop the last segment from the manifest: the reloaded engine must answer like an oracle over two segments
+        import struct
+        names = [b"seg_000001", b"seg_000002"]
+        with open(os.path.join(d, "manifest.bin"), "wb") as f:
+            f.write(struct.pack("<I", 2) + b"".join(struct.pack("<I", len(n)) + n for n in names))
+        eng.reload()
+        assert eng.num_segments == 2
+        ora2 = orc.Oracle(d)
+        try:
+            assert_same(eng.search_batch(queries, 10), ora2.search_batch(queries, 10), queries, "after reload onto two segments")
+        finally:
+            ora2.close()
+    finally:
+        eng.close()
+        ora.close()
+
+
 def test_and_extension_matches_derived_oracle(engines):
     g, eng, ora = engines("mid1")
     queries = workloads.cfg2_queries(64, 2002, g["params"]["vocab"]) + ["covid virus", "covid zzzzunknown", "covid covid virus"]
