@@ -160,6 +160,18 @@ int ns_segment_build_packed(ns_ctx* ctx, ns_seg* seg);
 int ns_ctx_use_packed(ns_ctx* ctx, int mode);
 /* on = 0: batches prepared from now on ignore impact streams (default: on = 1). */
 int ns_ctx_use_impacts(ns_ctx* ctx, int on);
+/* Skip tables (block metadata next to the reference's raw posting format, src/lexicon.cpp:104-128,
+ * which has none: the reference walks every list from its first posting, src/api_engine.cpp:470-481).  For every list
+ * given here the device stores, per 1024-doc cell of the segment's doc space, the index of the list's first posting in
+ * that cell (4 B per cell and list, built from the uploaded postings on the device).  Term groups that are scored in
+ * doc tiles (several frequent lists) then walk those cells and take exactly a list's postings of the cell instead of
+ * estimating how many to load and searching the cell's end by docId; every posting is still visited (`found`,
+ * src/api_engine.cpp:495) and results are bit-identical either way.  byte_off/counts as in ns_term_ref; a list that
+ * is not docId-ascending keeps no table (its groups take the cursor path); lists given again are left as they are.
+ * Meant for the frequent lists of a segment (the facade registers lists of >= n_docs / 512 postings at reload). */
+int ns_segment_build_skips(ns_ctx* ctx, ns_seg* seg, const uint64_t* byte_off, const uint32_t* counts, uint32_t n_lists);
+/* on = 0: batches prepared from now on ignore skip tables (default: on = 1). */
+int ns_ctx_use_skips(ns_ctx* ctx, int on);
 
 /* ---- one-shot search (host buffers in, host buffers out) ------------------------------------ */
 /* hits_out: Q*K entries, query-major, best first: score desc, then seg_id asc, then doc_id asc

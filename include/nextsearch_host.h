@@ -61,6 +61,8 @@ int nsh_engine_semantic_row(nsh_engine* e, uint32_t row, const char** term, cons
  * ns_segment_build_impacts / ns_ctx_use_impacts).  Not part of reload(): 8 B of HBM per posting. */
 int  nsh_engine_build_impacts(nsh_engine* e);
 void nsh_engine_use_impacts(nsh_engine* e, int on);
+/* reload() builds skip tables for the frequent lists of every segment (ns_segment_build_skips); on = 0: searches ignore them. */
+void nsh_engine_use_skips(nsh_engine* e, int on);
 /* Optional packed posting streams for every loaded segment (include/nextsearch_hip.h: ns_segment_build_packed /
  * ns_ctx_use_packed): 4-7 B read per posting instead of 12, same results.  Not part of reload(): 8 B of HBM per posting. */
 int  nsh_engine_build_packed(nsh_engine* e);

@@ -117,6 +117,25 @@ struct ns_seg {
     struct ImpList { uint32_t first = 0xFFFFFFFFu, count = 0, idf_bits = 0; };
     std::vector<ImpList> imp_tab;   // size is a power of two (or 0)
     size_t imp_lists = 0;
+    // Optional skip tables (ns_segment_build_skips; DevSeg::skips): `skip_tab` maps a list's first posting index to its count and
+    // to the index of its first table entry; every table has skip_entries() entries.
+    uint32_t* d_skips = nullptr;
+    std::vector<uint32_t*> skip_retired;    // outgrown blocks: batches prepared before the growth still point into them
+    uint64_t skip_cap = 0, skip_used = 0;   // entries allocated / in use
+    struct SkipList { uint32_t first = 0xFFFFFFFFu, count = 0, entry = 0; };
+    std::vector<SkipList> skip_tab;   // open-addressed, size a power of two (or 0)
+    size_t skip_lists = 0;
+    uint32_t skip_entries() const { return (n_docs + kSkipDocs - 1) / kSkipDocs + 2; }
+    // 1 + index of the first table entry of the list [first, first + count), or 0
+    uint32_t skip_of(uint32_t first, uint32_t count) const {
+        if (skip_tab.empty()) return 0;
+        const size_t mask = skip_tab.size() - 1;
+        for (size_t h = ((size_t)first * 0x9E3779B1u) & mask;; h = (h + 1) & mask) {
+            const SkipList& e = skip_tab[h];
+            if (e.first == first) return e.count == count ? e.entry + 1u : 0u;
+            if (e.first == 0xFFFFFFFFu) return 0;
+        }
+    }
     bool imp_has(uint32_t first, uint32_t count, uint32_t idf_bits) const {
         if (imp_tab.empty()) return false;
         const size_t mask = imp_tab.size() - 1;
@@ -164,6 +183,7 @@ struct ns_ctx {
     std::vector<DownSlot> down_slots;
     bool use_impacts = true;   // batches take the impact stream when every list they touch has one (ns_ctx_use_impacts)
     int use_packed = 1;        // 0 off; 1, 2: batches read the packed stream when every segment they touch has one (ns_ctx_use_packed)
+    bool use_skips = true;     // doc-tile groups walk the skip grid when their lists have skip tables (ns_ctx_use_skips)
     ns_prep* prep = nullptr;   // ns_batch_prepare's host threads and per-thread scratch, kept from batch to batch
     unsigned prep_threads = 0; // 0 = automatic (up to 8); 1 = prepare on the calling thread only (ns_ctx_set_host_threads)
 };
@@ -218,6 +238,7 @@ static constexpr uint32_t kDefaultSplitPostings = 32768;   // forced variants: p
 // top-K warm-up and its K-row partial result, so large K wants fewer, longer items (sweeps: profiles/r01).
 static constexpr uint32_t kSplitWorkSmallK = 98304, kSplitWorkLargeK = 131072;
 static constexpr uint64_t kWorkForeign = 8, kWorkTile = 2;
+static constexpr uint32_t kSkipMinCount = 64;   // shorter lists are never looked up in the skip registry (ns_segment_build_skips)
 // per-item, per-term constants of the launch-order key (fitted to per-item timestamps, tools/dbg/item_times.py)
 static constexpr uint64_t kItemTermGeneral = 10000, kItemTermThin = 3000, kItemTermTile = 8000;
 
@@ -348,6 +369,10 @@ static void seg_free_device(ns_seg* s) {
     (void)hipFree(s->d_pk_scores);
     (void)hipFree(s->d_nidx);
     (void)hipFree(s->d_ntab);
+    (void)hipFree(s->d_skips);
+    for (uint32_t* p : s->skip_retired) (void)hipFree(p);
+    s->skip_retired.clear();
+    s->d_skips = nullptr; s->skip_cap = s->skip_used = 0; s->skip_tab.clear(); s->skip_lists = 0;
     s->d_postings = nullptr; s->d_norm = nullptr; s->d_pnorm = nullptr; s->d_impacts = nullptr; s->d_packed = nullptr;
     s->d_pk_hdr = nullptr; s->d_pk_scores = nullptr; s->d_nidx = nullptr; s->d_ntab = nullptr;
 }
@@ -656,6 +681,137 @@ extern "C" int ns_segment_build_packed(ns_ctx* ctx, ns_seg* seg) {
     return NS_OK;
 }
 
+// ---- skip tables (block metadata next to the reference's posting format) --------------------------------
+// entry[l][i] = index of list l's first posting with docId >= i * kSkipDocs.  k_skip_fill: every entry = the list's end;
+// k_skip_build: one thread per posting p of a registered list — the grid cells after the previous posting's, up to its own,
+// start at p (docIds ascend inside a list, so every cell is written at most once); k_skip_check: a table is usable when
+// it starts at the list's first posting, never decreases and ends at the list's end (an unsorted list fails here and
+// simply keeps no table: its groups take the cursor path, which tolerates any order).
+__global__ void __launch_bounds__(256) k_skip_fill(uint32_t* __restrict__ sk, const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
+                                                   uint32_t per_list) {
+    const uint32_t l = blockIdx.y;
+    const uint32_t endp = starts[l] + counts[l];
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < per_list; i += gridDim.x * 256) sk[(uint64_t)l * per_list + i] = endp;
+}
+__global__ void __launch_bounds__(256) k_skip_build(const uint2* __restrict__ postings, uint32_t* __restrict__ sk, const uint32_t* __restrict__ starts,
+                                                    const uint32_t* __restrict__ counts, uint32_t per_list) {
+    const uint32_t l = blockIdx.y;
+    const uint32_t first = starts[l], n = counts[l];
+    uint32_t* row = sk + (uint64_t)l * per_list;
+    const uint32_t cells = per_list - 2;   // entries 0 .. cells are cell starts (cells = one past the last doc's), + 1 spare
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t d = postings[first + i].x / kSkipDocs;
+        uint32_t c0 = 0;
+        if (i) {
+            const uint32_t dp = postings[first + i - 1].x / kSkipDocs;
+            c0 = dp + 1;
+        }
+        for (uint32_t c = c0; c <= d && c <= cells; c++) row[c] = first + i;
+    }
+}
+__global__ void __launch_bounds__(256) k_skip_check(const uint2* __restrict__ postings, const uint32_t* __restrict__ sk, const uint32_t* __restrict__ starts,
+                                                    const uint32_t* __restrict__ counts, uint32_t per_list, uint32_t* __restrict__ bad) {
+    const uint32_t l = blockIdx.y;
+    const uint32_t first = starts[l], endp = first + counts[l];
+    const uint32_t* row = sk + (uint64_t)l * per_list;
+    bool b = false;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i + 1 < per_list; i += gridDim.x * 256) {
+        const uint32_t a = row[i], z = row[i + 1];
+        if (a > z || a < first || z > endp) b = true;
+        if (i == 0 && a != first) b = true;
+        if (i + 2 == per_list && (z != endp || a != endp)) b = true;
+        // the postings of cell i really are inside it (first and last suffice: the list ascends between table entries
+        // or the next cell's check fails)
+        if (i + 2 < per_list && a < z) {
+            if (postings[a].x / kSkipDocs != i || postings[z - 1].x / kSkipDocs != i) b = true;
+        }
+    }
+    if (b) bad[l] = 1u;
+}
+
+extern "C" int ns_segment_build_skips(ns_ctx* ctx, ns_seg* seg, const uint64_t* byte_off, const uint32_t* counts, uint32_t n_lists) {
+    if (!ctx || !seg) return fail(ctx, NS_E_INVAL, "ns_segment_build_skips: null argument");
+    if (seg->pending || seg->id >= ctx->segs.size() || ctx->segs[seg->id] != seg) return fail(ctx, NS_E_INVAL, "segment does not belong to this ctx");
+    if (n_lists && (!byte_off || !counts)) return fail(ctx, NS_E_INVAL, "null list arrays");
+    if (!n_lists || !seg->n_postings || !seg->n_docs) return NS_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    struct L { uint32_t first, count; };
+    std::vector<L> lists;
+    lists.reserve(n_lists);
+    for (uint32_t i = 0; i < n_lists; i++) {
+        if (byte_off[i] % 8 != 0) return fail(ctx, NS_E_INVAL, "list %u: byte offset %llu is not a multiple of 8", i, (unsigned long long)byte_off[i]);
+        const uint64_t first = byte_off[i] / 8;
+        if (first + counts[i] > seg->n_postings) return fail(ctx, NS_E_INVAL, "list %u runs past the segment's postings", i);
+        if (counts[i] && !seg->skip_of((uint32_t)first, counts[i])) lists.push_back({(uint32_t)first, counts[i]});
+    }
+    std::sort(lists.begin(), lists.end(), [](const L& a, const L& b) { return a.first < b.first || (a.first == b.first && a.count < b.count); });
+    lists.erase(std::unique(lists.begin(), lists.end(), [](const L& a, const L& b) { return a.first == b.first; }), lists.end());
+    if (lists.empty()) return NS_OK;
+    const uint32_t per_list = seg->skip_entries();
+    const size_t n = lists.size();
+    const uint64_t need = seg->skip_used + (uint64_t)n * per_list;
+    if (need >= (1ull << 32) - 1) return fail(ctx, NS_E_INVAL, "ns_segment_build_skips: %llu table entries do not fit 32 bits", (unsigned long long)need);
+    hipError_t e = hipSuccess;
+    if (need > seg->skip_cap) {   // grow (tables already built are kept: batches prepared earlier hold indices into them)
+        uint32_t* bigger = nullptr;
+        const uint64_t cap = std::max<uint64_t>(need, seg->skip_cap * 2);
+        e = hipMalloc((void**)&bigger, cap * 4);
+        if (e != hipSuccess) return fail(ctx, NS_E_NOMEM, "hipMalloc skip tables (%llu B): %s", (unsigned long long)(cap * 4), hipGetErrorString(e));
+        if (seg->d_skips) {   // the old block stays until the segment goes: earlier batches point into it
+            e = hipMemcpyAsync(bigger, seg->d_skips, seg->skip_used * 4, hipMemcpyDeviceToDevice, ctx->stream);
+            seg->skip_retired.push_back(seg->d_skips);
+        }
+        seg->d_skips = bigger;
+        seg->skip_cap = cap;
+        if (e != hipSuccess) return fail(ctx, NS_E_HIP, "ns_segment_build_skips: %s", hipGetErrorString(e));
+    }
+    std::vector<uint32_t> h(n * 3, 0u);
+    for (size_t i = 0; i < n; i++) { h[i] = lists[i].first; h[n + i] = lists[i].count; }
+    uint32_t* d_tmp = nullptr;
+    e = hipMalloc((void**)&d_tmp, n * 12);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_tmp, h.data(), n * 12, hipMemcpyHostToDevice, ctx->stream);
+    uint32_t* base = seg->d_skips + seg->skip_used;
+    if (e == hipSuccess) {
+        const dim3 g1((per_list + 255) / 256 > 64 ? 64 : (per_list + 255) / 256, (uint32_t)n);
+        hipLaunchKernelGGL(k_skip_fill, g1, dim3(256), 0, ctx->stream, base, d_tmp, d_tmp + n, per_list);
+        uint32_t cmax = 0;
+        for (const auto& l : lists) cmax = std::max(cmax, l.count);
+        const dim3 g2(std::min<uint32_t>((cmax + 255) / 256, 1024u), (uint32_t)n);
+        hipLaunchKernelGGL(k_skip_build, g2, dim3(256), 0, ctx->stream, seg->d_postings, base, d_tmp, d_tmp + n, per_list);
+        hipLaunchKernelGGL(k_skip_check, g1, dim3(256), 0, ctx->stream, seg->d_postings, base, d_tmp, d_tmp + n, per_list, d_tmp + 2 * n);
+        e = hipGetLastError();
+    }
+    std::vector<uint32_t> bad(n, 1u);
+    if (e == hipSuccess) e = hipMemcpyAsync(bad.data(), d_tmp + 2 * n, n * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_tmp);
+    if (e != hipSuccess) return fail(ctx, NS_E_HIP, "ns_segment_build_skips: %s", hipGetErrorString(e));
+    // registry
+    std::vector<ns_seg::SkipList> all;
+    for (const auto& t : seg->skip_tab) if (t.first != 0xFFFFFFFFu) all.push_back(t);
+    for (size_t i = 0; i < n; i++) {
+        if (bad[i]) continue;   // not ascending: no table
+        ns_seg::SkipList t; t.first = lists[i].first; t.count = lists[i].count; t.entry = (uint32_t)(seg->skip_used + i * per_list);
+        all.push_back(t);
+    }
+    seg->skip_used = need;
+    size_t cap = 16;
+    while (cap < all.size() * 2) cap <<= 1;
+    std::vector<ns_seg::SkipList> tab(cap);
+    for (const auto& t : all)
+        for (size_t hh = ((size_t)t.first * 0x9E3779B1u) & (cap - 1);; hh = (hh + 1) & (cap - 1))
+            if (tab[hh].first == 0xFFFFFFFFu) { tab[hh] = t; break; }
+    seg->skip_tab.swap(tab);
+    seg->skip_lists = all.size();
+    return NS_OK;
+}
+
+extern "C" int ns_ctx_use_skips(ns_ctx* ctx, int on) {
+    if (!ctx) return NS_E_INVAL;
+    ctx->use_skips = on != 0;
+    return NS_OK;
+}
+
 extern "C" int ns_ctx_use_packed(ns_ctx* ctx, int on) {
     if (!ctx) return NS_E_INVAL;
     if (on < 0 || on > 2) return fail(ctx, NS_E_INVAL, "ns_ctx_use_packed: mode %d (0, 1 or 2)", on);
@@ -809,7 +965,7 @@ static hipError_t batch_alloc(ns_batch* b, void** dptr, size_t n) {
 // result (descriptor bytes, launch order) is independent of the number of threads.
 namespace {
 
-struct HostGroup { DevGroup g; uint32_t query; uint64_t cost; uint64_t cmax; uint64_t work; bool wave; uint8_t cls; bool fast_div; bool signed_in; };
+struct HostGroup { DevGroup g; uint32_t query; uint64_t cost; uint64_t cmax; uint64_t work; bool wave; uint8_t cls; bool fast_div; bool signed_in; bool grid; };
 
 constexpr uint32_t kOrderBuckets = 2048;   // launch-order key: 6 bits of exponent x 5 bits of mantissa of the estimated run time
 inline uint32_t order_bucket(uint64_t c) {  // descending: bucket 0 holds the longest items
@@ -901,6 +1057,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
             d.pk_hdr = s->d_pk_hdr;
             d.ntab = s->d_ntab;
             d.pk_scores = s->d_pk_scores;
+            d.skips = s->d_skips;
             d.norm = s->d_norm;
             d.n_postings = s->n_postings;
             d.n_docs = s->n_docs;
@@ -989,6 +1146,16 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                     // work estimate in units of one streamed driver posting (measured, profiles/r01): a foreign
                     // posting (claim, accumulate, read back) costs ~8x, a doc-tile posting ~2x
                     hg.work = !auto_mode ? hg.cost : (hg.cls == 2 ? hg.cost * kWorkTile : hg.cmax + rest * kWorkForeign);
+                    // doc-tile groups walk the skip grid when some list of theirs has a skip table (ns_segment_build_skips)
+                    if (auto_mode && hg.cls == 2 && hg.wave && ctx->use_skips && !ctx->segs[sid]->skip_tab.empty()) {
+                        const ns_seg* sg_ = ctx->segs[sid];
+                        for (uint32_t ti = hg.g.term_begin; ti < (uint32_t)S.dterms.size(); ti++) {
+                            DevTerm& dt = S.dterms[ti];
+                            if (dt.count < kSkipMinCount) continue;
+                            dt.skip = sg_->skip_of((uint32_t)dt.list_off, dt.count);
+                            if (dt.skip) hg.grid = true;
+                        }
+                    }
                 }
                 if (!hg.wave) {
                     hg.g.bounds_off = S.bounds_total;   // local; the slice's base is added in phase B
@@ -1077,9 +1244,13 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                         it.term_count = hg.g.term_count;
                         it.doc_lo = (uint32_t)((uint64_t)sg.n_docs * i / ns);
                         it.doc_hi = (uint32_t)((uint64_t)sg.n_docs * (i + 1) / ns);
+                        if (hg.grid) {   // ranges of a skip-grid group start and end on the grid
+                            it.doc_lo -= it.doc_lo % kSkipDocs;
+                            if (i + 1 < ns) it.doc_hi -= it.doc_hi % kSkipDocs;
+                        }
                         if (it.doc_hi <= it.doc_lo) continue;
                         it.out_slot = S.n_rows++;
-                        it.whole = (ns == 1 ? 1u : 0u) | (hg.fast_div ? 8u : 0u) | (hg.signed_in ? 16u : 0u);
+                        it.whole = (ns == 1 ? 1u : 0u) | (hg.fast_div ? 8u : 0u) | (hg.signed_in ? 16u : 0u) | (hg.grid ? 32u : 0u);
                         // auto mode: very dense groups take the doc-tile body (bit 1), groups with thin non-driver lists the small foreign budget (bit 2)
                         if (auto_mode) it.whole |= (hg.cls == 2 ? 2u : 0u) | (hg.cls == 1 ? 4u : 0u);
                         S.witems.push_back(it);

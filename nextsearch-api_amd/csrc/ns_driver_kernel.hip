@@ -51,7 +51,6 @@ __device__ unsigned long long g_ns_cnt[16];
 template <bool IMP, int PKM>
 __device__ __forceinline__ void pk_decode_round(const DevSeg& seg, const uint32_t blk, const int lane, uint32_t (&doc)[4], float (&tf)[4],
                                                 float (&nr)[4], uint32_t (&sbits)[4]) {
-    typedef const __attribute__((address_space(1))) uint32_t* gp_u32;
     const gp_u32 pb = (gp_u32)seg.packed + (size_t)blk * kPkStrideDwords + (uint32_t)lane;
     const uint32_t d0 = pb[kPkDoc], d1 = pb[kPkDoc + 64];
     uint32_t t = 0, na = 0, nb = 0;

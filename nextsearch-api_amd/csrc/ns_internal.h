@@ -27,6 +27,8 @@ static constexpr uint32_t kTileEmptyBits = 0xFFFFFFFFu;
 static constexpr uint32_t kPkBlock = 256;
 static constexpr uint32_t kPkStrideDwords = 512;   // 2 KB
 static constexpr uint32_t kPkTf = 0, kPkNormA = 64, kPkNormB = 128, kPkDoc = 192;
+// Skip tables: one entry per kSkipDocs docs == the doc-tile body's tile (k_uscore: 2 * HK slots).
+static constexpr uint32_t kSkipDocs = 1024;
 
 struct DevSeg {
     const uint2* postings;   // {docId, tf} pairs, all inverted files of the segment back to back
@@ -39,6 +41,10 @@ struct DevSeg {
     const uint2* pk_hdr;     // per block: {base docId, doc width code}
     const float* ntab;       // the segment's distinct norms; a posting carries a 16-bit index into it
     const float* pk_scores;  // optional, per block 4 x 64 fp32 term scores (chunk-major): the impact stream in packed form
+    // optional skip tables (ns_segment_build_skips; SURVEY §8 f2, block metadata): for a registered list, entry i = index
+    // (into `postings`) of its first posting with docId >= i * kSkipDocs, i = 0 .. ceil(n_docs / kSkipDocs); one more entry
+    // (= the list's end) so that the entry after next can always be read.  nullptr if never built
+    const uint32_t* skips;
     uint64_t     n_postings;
     uint32_t     n_docs;
     uint32_t     n_tiles;    // ceil(n_docs / tile_docs)
@@ -51,7 +57,8 @@ struct DevTerm {
     float    idf;        // bm25_idf(N, df), computed on the host with glibc logf
     float    weight;     // qweight
     uint32_t seg;
-    uint32_t pad0, pad1;
+    uint32_t skip;       // 0: no skip table; else 1 + index of the list's first entry in DevSeg::skips
+    uint32_t pad1;
 };
 
 // Work item == one workgroup of k_score: one (query, segment) term group over a range of doc tiles.
@@ -81,6 +88,8 @@ struct DevWItem {
                            // bit 2: thin foreign lists; bit 3: idf and norms in the short-division range (ns_div_short);
                            // bit 4: some idf or weight of the group has its sign bit set (a contribution may be -0.0f: the
                            //        driver stream then canonicalises its private scores as the reference's 0.0f + x does)
+                           // bit 5: doc-tile body on the skip grid: doc_lo is a multiple of kSkipDocs, tiles are grid cells,
+                           //        and the terms with DevTerm::skip != 0 take their postings of a tile from the skip table
 };
 
 // Term group == the (query, segment) unit the boundary prepass works on.

@@ -43,6 +43,12 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
     const gp_u2 postings = (gp_u2)seg.postings;
     const gp_f32 pnorm = (gp_f32)seg.pnorm;
     const gp_u2 stream = IMP ? (gp_u2)seg.impacts : postings;   // IMP: {docId, precomputed term score bits} (see dscore_body)
+    // Skip grid (DevWItem::whole bit 5; the host sets it only for TD == kSkipDocs and a doc_lo on the grid): tiles are the
+    // cells of the segment's skip tables, and a term that has a table takes EXACTLY its postings of the tile — entry[tile]
+    // .. entry[tile + 1] — instead of estimating a round and finding the tile's end by comparing docIds: no partly used
+    // rounds, no cursor search.  Terms without a table (short lists) keep their cursors, in the same tiles.
+    const bool grid = TD == (int)kSkipDocs && (__builtin_amdgcn_readfirstlane((int)it.whole) & 32) != 0;
+    const gp_u32 skips = (gp_u32)seg.skips;
 
     const float4 sent4 = make_float4(__uint_as_float(kTileEmptyBits), __uint_as_float(kTileEmptyBits),
                                      __uint_as_float(kTileEmptyBits), __uint_as_float(kTileEmptyBits));   // see ns_internal.h
@@ -57,21 +63,35 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
 
     // ---- lane t owns term t: absolute posting cursor, end, and the docId at the cursor (~0: exhausted).
     //      Posting indices are 32-bit: upload rejects segments of >= 2^32 postings. ----
-    uint32_t cur = 0, end = 0, nd = 0xFFFFFFFFu, idf_bits = 0, wq_bits = 0;
+    //      A term on the skip grid: `cur` .. `end` are its postings of the CURRENT tile, `nxt` the end of the next tile's
+    //      (read one tile ahead), `skb` the index of its table entry for tile 0; its `nd` stays ~0. ----
+    uint32_t cur = 0, end = 0, nd = 0xFFFFFFFFu, idf_bits = 0, wq_bits = 0, nxt = 0, skb = 0;
+    bool on_grid = false;
     if ((uint32_t)lane < T) {
         const DevTerm tm = terms[it.term_begin + lane];
         idf_bits = __float_as_uint(tm.idf);
         wq_bits = __float_as_uint(tm.weight);
-        end = tm.count;
-        if (!(it.whole & 1u)) {
-            const uint2* lst = seg.postings + tm.list_off;
-            list_range(lst, tm.count, it.doc_lo, it.doc_hi, seg.n_docs, cur, end);
-            if (end < cur) end = cur;
+        if (grid && tm.skip != 0u) {
+            on_grid = true;
+            skb = tm.skip - 1u;
+            const uint32_t t0 = skb + it.doc_lo / (uint32_t)TD;
+            cur = skips[t0];
+            end = skips[t0 + 1u];
+            nxt = skips[t0 + 2u];
+            if (end < cur) end = cur;   // tables are checked when they are built; a wrapped count must never happen
+        } else {
+            end = tm.count;
+            if (!(it.whole & 1u)) {
+                const uint2* lst = seg.postings + tm.list_off;
+                list_range(lst, tm.count, it.doc_lo, it.doc_hi, seg.n_docs, cur, end);
+                if (end < cur) end = cur;
+            }
+            cur += (uint32_t)tm.list_off;
+            end += (uint32_t)tm.list_off;
+            if (cur < end) { const nat_u2 pv = postings[cur]; nd = pv.x; }
         }
-        cur += (uint32_t)tm.list_off;
-        end += (uint32_t)tm.list_off;
-        if (cur < end) { const nat_u2 pv = postings[cur]; nd = pv.x; }
     }
+    const uint64_t gridm = grid ? wballot(on_grid) : 0ull;
 
     const uint32_t last_doc = it.doc_hi - 1;   // host guarantees doc_hi > doc_lo and doc_hi <= n_docs
     float theta = -__builtin_inff();
@@ -115,7 +135,14 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
     uint64_t act = 0ull;
     bool done = false;
 #define NS_TILE_HEADER()                                                                           \
-    {                                                                                              \
+    if (gridm != 0ull) {   /* grid cells one after the other (lo stays on the grid) */             \
+        done = lo > last_doc;                                                                      \
+        if (!done) {                                                                               \
+            hi = (last_doc - lo >= (uint32_t)TD) ? (lo + (uint32_t)(TD - 1)) : last_doc;           \
+            frac = (float)(hi - lo + 1u) * __builtin_amdgcn_rcpf((float)(last_doc - lo + 1u));     \
+            act = wballot(nd <= hi) | (wballot(end > cur) & gridm);                                \
+        }                                                                                          \
+    } else {                                                                                       \
         const uint32_t mind_ = wave_min_dpp(nd);                                                   \
         done = mind_ > last_doc;                                                                   \
         if (!done) {                                                                               \
@@ -129,6 +156,7 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
     NS_TILE_HEADER();
     while (!done) {
         const uint32_t tile_lo = lo, tile_hi = hi;
+        const bool touched = act != 0ull;            // a grid cell may hold no posting of the group at all
         NS_TCNT(1, 1);                               // tiles
         NS_TCNT(2, __popcll(act));                   // (term, tile) visits
         // ---- the terms that have postings in this tile, in query order (the fp32 accumulation order) ----
@@ -139,11 +167,53 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
             const uint32_t s_end = rdlane(end, t);
             const float idf = __uint_as_float(rdlane(idf_bits, t));
             const float wq = __uint_as_float(rdlane(wq_bits, t));
-            uint32_t want = 16u + (uint32_t)((float)(s_end - s_cur) * frac * 1.125f);
+            const bool exact = ((gridm >> t) & 1ull) != 0ull;   // [s_cur, s_end) are the term's postings of this tile, all of them
+            uint32_t want = exact ? (uint32_t)(E * 64) : 16u + (uint32_t)((float)(s_end - s_cur) * frac * 1.125f);
             uint32_t s_nd = 0xFFFFFFFFu;
             for (;;) {
                 const uint32_t remd = s_end - s_cur;
                 if (remd == 0) break;
+                if (exact && remd >= (uint32_t)(E * 64)) {
+                    // A FULL round on the skip grid: 256 postings that are all in this tile.  No lane masks, no exec
+                    // games, no per-chunk branches: the arithmetic of the general round below with every lane live.
+                    // (Measured next to it: ALL rounds of such a term as straight-line code, lanes past the segment's end
+                    // parked on dummy slots — fewer instructions, but slower on mixed batches; profiles/r02/ab.)
+                    NS_ISSUE(ps, nr, s_cur, (uint32_t)(E * 64));
+                    NS_TCNT(3, 1); NS_TCNT(4, E); NS_TCNT(5, E * 64);
+                    float xq[E], oldq[E];
+                    uint32_t slq[E];
+#pragma unroll
+                    for (int j0 = 0; j0 < E; j0 += 2) {
+                        float num_[2], den_[2], q_[2];
+#pragma unroll
+                        for (int jj = 0; jj < 2; jj++) {
+                            const float tf = (float)ps[j0 + jj].y;
+                            den_[jj] = tf + nr[j0 + jj];
+                            num_[jj] = idf * (tf * (1.2f + 1.0f));
+                        }
+                        if (IMP) { q_[0] = __uint_as_float(ps[j0].y); q_[1] = __uint_as_float(ps[j0 + 1].y); }
+                        else ns_div_n<2>(q_, num_, den_, fast_div);
+#pragma unroll
+                        for (int jj = 0; jj < 2; jj++) {
+                            xq[j0 + jj] = q_[jj];
+                            slq[j0 + jj] = (ps[j0 + jj].x - tile_lo) & (uint32_t)(TD - 1);
+                            oldq[j0 + jj] = vals[slq[j0 + jj]];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < E; j++) {
+                        const bool fresh_ = __float_as_uint(oldq[j]) == kTileEmptyBits;
+                        if (!AND) found_s += (uint32_t)__popcll(wballot(fresh_));
+                        oldq[j] = fresh_ ? 0.0f : oldq[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < E; j++) {
+                        vals[slq[j]] = oldq[j] + wq * xq[j];
+                        if (AND) mcnt[slq[j]] = (uint8_t)(mcnt[slq[j]] + 1);
+                    }
+                    s_cur += (uint32_t)(E * 64);
+                    continue;
+                }
                 uint32_t n;
                 if (kPrefetch && pf_start == s_cur) {   // the prefetched round is this one
                     n = pf_n;
@@ -156,7 +226,7 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
                 NS_TCNT(3, 1);                       // rounds
                 NS_TCNT(4, (n + 63) / 64);           // chunks loaded
                 const bool expect_more = want > n;
-                want = expect_more ? (want - n) : 64u;
+                if (!exact) want = expect_more ? (want - n) : 64u;   // exact: every round is as large as what is left allows
                 // ---- prefetch the round expected next ----
                 pf_start = 0xFFFFFFFFu;
                 if (!kPrefetch) {
@@ -187,7 +257,7 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
                         const int j = (J0) + jj;                                                   \
                         const uint32_t left = (n > (uint32_t)(j * 64)) ? (n - (uint32_t)(j * 64)) : 0u;   /* scalar */ \
                         const uint64_t nmask = (left >= 64u) ? ~0ull : ((1ull << left) - 1ull);    \
-                        takem[j] = wballot(ps[j].x <= tile_hi) & nmask;                            \
+                        takem[j] = exact ? nmask : (wballot(ps[j].x <= tile_hi) & nmask);          \
                         cnt += (uint32_t)__popcll(takem[j]);                                       \
                         const float tf = (float)ps[j].y;                                           \
                         den_[jj] = tf + nr[j];                                                     \
@@ -241,6 +311,13 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
         if (tile_hi >= last_doc) { done = true; }
         else {
             lo = tile_hi + 1u;
+            if (gridm != 0ull) {   // the next cell: its postings end where the entry read one tile ago says; read the one after
+                if (on_grid) {
+                    cur = end;
+                    end = nxt < cur ? cur : nxt;
+                    nxt = skips[skb + lo / (uint32_t)TD + 2u];
+                }
+            }
             NS_TILE_HEADER();
             if (kPrefetch && !done && act != 0ull) {
                 const uint32_t t0 = (uint32_t)__builtin_ctzll(act);
@@ -256,6 +333,7 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
 
         // ---- read the tile back: candidates, reset (and, for the conjunctive extension, found) ----
         bool ge_mode = false;   // after a shrink INSIDE this tile, ties with theta may still win on docId
+        if (touched) {
 #pragma unroll
         for (int g = 0; g < NG; g++) {
             const float4 q = v4[g * 64 + lane];
@@ -298,6 +376,7 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
                     }
                 }
             }
+        }
         }
         wave_sync();
         if (ncand > (uint32_t)(CB - 64)) ncand = wave_shrink_cb<CB>(cand, ncand, nsorted, theta, K, lane);   // keep room for one more step of offers
@@ -389,7 +468,7 @@ __global__ void __launch_bounds__(64 * kUscoreWavesPerBlock) __attribute__((amdg
     DevWItem it = items[item_idx];
     const bool tiles = (it.whole & 2u) != 0;
     const bool thin = (it.whole & 4u) != 0;   // the non-driver lists are thin: smallest foreign budget
-    it.whole &= 25u;   // bit 0: whole segment, bit 3: short division, bit 4: signed inputs
+    it.whole &= 57u;   // bit 0: whole segment, bit 3: short division, bit 4: signed inputs, bit 5: skip grid (doc tiles)
     if (thin)
         dscore_body<HK / 2, 64, AND, CB, IMP, PK>(it, terms, segs, s_tbl[wave], s_vals[wave], s_mcnt[wave], s_cand[wave],
                                  s_tab[wave], s_aux[wave], out_hits, out_nhits, out_found, K, lane);

@@ -118,16 +118,91 @@ __device__ __forceinline__ uint32_t wave_shrink(uint64_t* cand, uint32_t n, floa
 }
 // CB-aware form used by the scoring bodies: the merge variant (and its `sorted` bookkeeping) exists only in
 // the 256-entry instantiations; `sorted` is updated to the new count (a shrink leaves a descending run)
+// ---- the candidate buffer sorted in REGISTERS ----
+// The in-LDS network above pays an LDS round trip per stage (72 stages over 256 entries: the shrink of a K = 100 batch
+// took a third of its doc-tile items' time).  Here lane l holds entries l*R .. l*R + R - 1 (R = CB / 64): the stages with
+// a partner distance below R are compare-exchanges between registers of one lane, the others exchange with lane l ^ m
+// (quad DPP for m = 1, 2; the LDS crossbar without touching memory — ds_swizzle / ds_bpermute — for m = 4 .. 32).
+// Keys are unique except for the zero padding, so every correct network yields the same order as the one above.
+template <int M>
+__device__ __forceinline__ uint32_t lane_xor_u32(uint32_t v, int lane) {
+    if constexpr (M == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);        // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    else if constexpr (M < 32) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (M << 10) | 0x1F);          // bit mode: xor M inside 32 lanes
+    else return (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, (int)v);
+}
+template <int R, int KK, int J>
+__device__ __forceinline__ void wave_sort_stage(uint64_t (&k)[R], int lane) {
+    // entry index i = lane * R + r; stage (KK, J): partner i ^ J, descending where (i & KK) == 0
+    if constexpr (J < R) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (r & J) continue;
+            const uint64_t a = k[r], b = k[r | J];
+            bool desc;
+            if constexpr (KK < R) desc = (r & KK) == 0;
+            else desc = ((lane * R) & KK) == 0;
+            const bool sw = desc ? (a < b) : (a > b);
+            k[r] = sw ? b : a;
+            k[r | J] = sw ? a : b;
+        }
+    } else {
+        constexpr int M = J / R;
+        const bool keep_max = ((lane & M) == 0) == (((lane * R) & KK) == 0);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint64_t x = k[r];
+            const uint64_t y = ((uint64_t)lane_xor_u32<M>((uint32_t)(x >> 32), lane) << 32) | lane_xor_u32<M>((uint32_t)x, lane);
+            const bool take = keep_max ? (y > x) : (y < x);
+            k[r] = take ? y : x;
+        }
+    }
+}
+template <int R, int KK, int J>
+__device__ __forceinline__ void wave_sort_merge_steps(uint64_t (&k)[R], int lane) {
+    wave_sort_stage<R, KK, J>(k, lane);
+    if constexpr (J > 1) wave_sort_merge_steps<R, KK, J / 2>(k, lane);
+}
+template <int R, int KK>
+__device__ __forceinline__ void wave_sort_levels(uint64_t (&k)[R], int lane) {
+    if constexpr (KK > 2) wave_sort_levels<R, KK / 2>(k, lane);
+    wave_sort_merge_steps<R, KK, KK / 2>(k, lane);
+}
+// cand[0..n) -> sorted descending in place (entries n .. 64 R - 1 come back as zero padding), by one wave
+template <int R>
+__device__ __forceinline__ void wave_sort_desc_regs(uint64_t* cand, uint32_t n, int lane) {
+    uint64_t k[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t i = (uint32_t)(lane * R + r);
+        k[r] = i < n ? cand[i] : 0ull;
+    }
+    wave_sort_levels<R, 64 * R>(k, lane);
+    wave_sync();
+#pragma unroll
+    for (int r = 0; r < R; r++) cand[lane * R + r] = k[r];
+    wave_sync();
+}
+template <int CB>
+__device__ __noinline__ uint64_t wave_shrink_regs_packed(uint64_t* cand, uint32_t n, uint32_t theta_bits, uint32_t K, int lane) {
+    wave_sync();
+    wave_sort_desc_regs<CB / 64>(cand, n, lane);
+    if (n >= K) {
+        theta_bits = __float_as_uint(unorder_bits((uint32_t)(cand[K - 1] >> 32)));   // same address in all lanes: broadcast
+        n = K;
+    }
+    return ((uint64_t)theta_bits << 32) | n;
+}
+
 template <int CB>
 __device__ __forceinline__ uint32_t wave_shrink_cb(uint64_t* cand, uint32_t n, uint32_t& sorted, float& theta, uint32_t K, int lane) {
-    if constexpr (CB > 128) {
-        uint64_t r = wave_shrink_merge_packed(cand, n, sorted, __float_as_uint(theta), K, lane);
-        theta = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(r >> 32)));
-        sorted = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r);
-        return sorted;
-    } else {
-        return wave_shrink(cand, n, theta, K, lane);
-    }
+    static_assert(CB == 128 || CB == 256, "candidate buffer of 128 or 256 entries");
+    const uint64_t r = wave_shrink_regs_packed<CB>(cand, n, __float_as_uint(theta), K, lane);
+    // wave-uniform by construction; telling the compiler keeps theta, the candidate count and every
+    // decision that depends on them in SGPRs (scalar branches instead of exec-masked vector code)
+    theta = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(r >> 32)));
+    sorted = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r);
+    return sorted;
 }
 
 // ballot straight from the compare (HIP's __ballot goes through an int and costs two extra vector instructions)
@@ -261,6 +336,7 @@ typedef unsigned int nat_u2 __attribute__((ext_vector_type(2)));
 // generic (flat_*) loads also tick lgkmcnt, which would serialise them with the LDS phases
 typedef const __attribute__((address_space(1))) nat_u2* gp_u2;
 typedef const __attribute__((address_space(1))) float* gp_f32;
+typedef const __attribute__((address_space(1))) uint32_t* gp_u32;
 
 // per-posting norm, built once at upload: pnorm[i] = norm[postings[i].docId]
 __global__ void k_pnorm(const uint2* __restrict__ postings, const float* __restrict__ norm, float* __restrict__ pnorm,

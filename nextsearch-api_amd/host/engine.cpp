@@ -54,6 +54,27 @@ static bool upload_segment(ns_ctx* ctx, uint32_t seg_id, nsx::SegmentData& s, ns
         (void)ns_segment_release(ctx, dev);
         return false;
     }
+    // skip tables for the segment's frequent lists (ns_segment_build_skips: 4 B per list and 1024-doc cell).  The
+    // reference's lists carry no block metadata (src/lexicon.cpp:104-128); this is built from the uploaded postings.
+    {
+        const uint32_t min_count = std::max<uint32_t>(64u, s.N / 512u);
+        std::vector<uint64_t> off;
+        std::vector<uint32_t> cnt;
+        for (const auto& kv : s.lex) {
+            const nsx::LexEntry& e = kv.second;
+            if (e.df == 0 || e.count < min_count) continue;
+            off.push_back(s.list_byte_offset(e));
+            cnt.push_back(e.count);
+        }
+        if (!off.empty()) {
+            rc = ns_segment_build_skips(ctx, dev, off.data(), cnt.data(), (uint32_t)off.size());
+            if (rc != NS_OK) {
+                err = std::string("ns_segment_build_skips: ") + ns_last_error(ctx);
+                (void)ns_segment_release(ctx, dev);
+                return false;
+            }
+        }
+    }
     *out = dev;
     return true;
 }
@@ -204,6 +225,8 @@ bool Engine::build_packed() {
 }
 
 void Engine::use_packed(int mode) { std::lock_guard<std::recursive_mutex> lock(mtx_); if (ctx_) ns_ctx_use_packed(ctx_, mode); }
+
+void Engine::use_skips(bool on) { std::lock_guard<std::recursive_mutex> lock(mtx_); if (ctx_) ns_ctx_use_skips(ctx_, on ? 1 : 0); }
 
 void Engine::use_impacts(bool on) { std::lock_guard<std::recursive_mutex> lock(mtx_); if (ctx_) ns_ctx_use_impacts(ctx_, on ? 1 : 0); }
 

@@ -65,6 +65,8 @@ public:
     // (ns_segment_build_impacts); searches then read {docId, score} instead of {docId, tf} + norm.  Same results.
     bool build_impacts();
     void use_impacts(bool on);
+    // reload() builds skip tables for every segment's frequent lists (ns_segment_build_skips); off = searches ignore them
+    void use_skips(bool on);
     // Optional: blocks of 256 postings with 8/16/32-bit docId offsets, 8-bit tf and a 16-bit norm index,
     // built on the device next to the raw stream (ns_segment_build_packed); the driver streams then read 4-7 B per posting
     // instead of 12.  Same results.

@@ -334,6 +334,8 @@ extern "C" int nsh_engine_build_packed(nsh_engine* e) { try {
 }
 extern "C" void nsh_engine_use_packed(nsh_engine* e, int on) { try { if (e) e->eng.use_packed(on); } NSH_CATCH_VOID(e, "nsh_engine_use_packed")
 }
+extern "C" void nsh_engine_use_skips(nsh_engine* e, int on) { try { if (e) e->eng.use_skips(on != 0);  } NSH_CATCH_VOID(e, "nsh_engine_use_skips")
+}
 extern "C" void nsh_engine_use_impacts(nsh_engine* e, int on) { try { if (e) e->eng.use_impacts(on != 0);  } NSH_CATCH_VOID(e, "nsh_engine_use_impacts")
 }
 

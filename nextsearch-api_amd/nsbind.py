@@ -55,7 +55,7 @@ HIP_SYMBOLS = [
     "ns_ctx_create", "ns_ctx_destroy", "ns_ctx_set_stream", "ns_last_error", "ns_device_name",
     "ns_segment_upload", "ns_segment_release", "ns_segment_upload_begin", "ns_segment_upload_append", "ns_segment_upload_end", "ns_search_batch", "ns_batch_prepare",
     "ns_batch_bind_outputs", "ns_batch_run", "ns_batch_stream", "ns_batch_gap_ms", "ns_batch_sync", "ns_batch_fetch", "ns_batch_get_info",
-    "ns_batch_destroy", "ns_set_tuning", "ns_segment_build_impacts", "ns_ctx_use_impacts", "ns_ctx_set_host_threads", "ns_ctx_set_overlap", "ns_segment_build_packed", "ns_ctx_use_packed",
+    "ns_batch_destroy", "ns_set_tuning", "ns_segment_build_impacts", "ns_ctx_use_impacts", "ns_ctx_set_host_threads", "ns_ctx_set_overlap", "ns_segment_build_packed", "ns_ctx_use_packed", "ns_segment_build_skips", "ns_ctx_use_skips",
     "ns_invert_forward", "ns_merge_rank_rows", "ns_sem_upload", "ns_sem_release", "ns_sem_topk",
 ]
 HOST_SYMBOLS = [
@@ -64,7 +64,7 @@ HOST_SYMBOLS = [
     "nsh_engine_segment_doc_len", "nsh_engine_segment_postings", "nsh_engine_lookup", "nsh_bm25_idf",
     "nsh_base_terms", "nsh_engine_build_refs", "nsh_engine_search_json", "nsh_free",
     "nsh_engine_search_batch", "nsh_engine_prepare", "nsh_engine_doc_metadata", "nsh_engine_hits_to_json", "nsh_engine_search_batch_json",
-    "nsh_engine_build_impacts", "nsh_engine_use_impacts", "nsh_engine_build_packed", "nsh_engine_use_packed", "nsh_invert_segment", "nsh_invert_error",
+    "nsh_engine_build_impacts", "nsh_engine_use_impacts", "nsh_engine_build_packed", "nsh_engine_use_packed", "nsh_engine_use_skips", "nsh_invert_segment", "nsh_invert_error",
     "nsh_engine_semantic_info", "nsh_engine_expand", "nsh_engine_semantic_row", "nsh_engine_set_cache", "nsh_engine_cache_size",
 ]
 
@@ -95,6 +95,8 @@ def hip_lib():
         L.ns_segment_upload_end.argtypes = [vp, vp]
         L.ns_segment_build_impacts.argtypes = [vp, vp, vp, vp, vp, u32]
         L.ns_ctx_use_impacts.argtypes = [vp, i32]
+        L.ns_segment_build_skips.argtypes = [vp, vp, vp, vp, u32]
+        L.ns_ctx_use_skips.argtypes = [vp, i32]
         L.ns_ctx_set_host_threads.argtypes = [vp, u32]
         L.ns_ctx_set_overlap.argtypes = [vp, i32]
         L.ns_segment_build_packed.argtypes = [vp, vp]
@@ -175,6 +177,8 @@ def host_lib():
         L.nsh_engine_build_impacts.argtypes = [vp]
         L.nsh_engine_use_impacts.argtypes = [vp, i32]
         L.nsh_engine_use_impacts.restype = None
+        L.nsh_engine_use_skips.argtypes = [vp, i32]
+        L.nsh_engine_use_skips.restype = None
         L.nsh_engine_build_packed.argtypes = [vp]
         L.nsh_engine_use_packed.argtypes = [vp, i32]
         L.nsh_engine_use_packed.restype = None
@@ -445,6 +449,10 @@ class Engine:
     def use_packed(self, mode):
         """0 off; 1 packed docIds + tf, norms from the fp32 norm stream (default); 2 norms through the 16-bit norm index."""
         self._L.nsh_engine_use_packed(self.h, int(mode))
+
+    def use_skips(self, on):
+        """Searches walk the skip tables reload() built (default) or ignore them."""
+        self._L.nsh_engine_use_skips(self.h, 1 if on else 0)
 
     def use_impacts(self, on):
         self._L.nsh_engine_use_impacts(self.h, 1 if on else 0)

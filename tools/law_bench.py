@@ -74,6 +74,7 @@ def laws():
     L["cfg5_q2048"] = (workloads.cfg5_queries(2048, 2005), 10)
     L["cfg5_q512"] = (workloads.cfg5_queries(512, 2005), 10)
     L["cfg3_k64"] = (workloads.cfg3_queries(), 64)
+    L["hot5_k10"] = ([" ".join(T(r) for r in (1, 2, 3, 4, 5))] * 1024, 10)
     return L
 
 
@@ -85,6 +86,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--impacts", action="store_true", help="build the optional impact streams first")
     ap.add_argument("--packed", type=int, default=0, help="build the packed posting streams first and read them in this mode (1: norms from the fp32 stream, 2: through the 16-bit norm index)")
+    ap.add_argument("--no-skips", action="store_true", help="ignore the skip tables reload() built")
     ap.add_argument("--segments", type=int, default=1, help="segments of --docs docs each (20 x 1M docs = 1.1 GB of postings: beyond the 256 MiB Infinity Cache)")
     ap.add_argument("--docs", type=int, default=1_000_000)
     ap.add_argument("--qscale", type=float, default=1.0, help="keep only this fraction of every law's queries (every query scans every segment)")
@@ -99,6 +101,8 @@ def main():
     if args.packed:
         eng.build_packed()
         eng.use_packed(args.packed)
+    if args.no_skips:
+        eng.use_skips(False)
     L = laws()
     # every list of ranks 1..4096 scanned by exactly one query: each posting byte is read once per launch
     if args.qscale != 1.0:
