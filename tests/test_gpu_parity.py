@@ -172,6 +172,71 @@ def test_zero_tf_postings_and_signed_weights(variant, split):
         L.ns_ctx_destroy(ctx)
 
 
+@pytest.mark.parametrize("variant,split,skips", [(0, 0, 2), (0, 0, 1), (0, 0, 0), (0, 700, 2), (19, 0, 0), (18, 300, 0), (12, 0, 0)])
+def test_equal_scores_in_doc_tiles_and_skip_tables(variant, split, skips):
+    """Every doc has the same length and every posting of a list the same tf, so ALL docs of a dense group score
+    equal: the K best are the K smallest docIds (canonical tie order), whatever order the tile read-back offers the
+    slots in and wherever the candidate buffer is shrunk (a shrink inside a tile leaves ties with the threshold that
+    still win on docId).  Raw C-ABI; with skip tables (ns_segment_build_skips) for all lists (2), for some (1: the
+    others keep their cursors inside the same grid tiles) or none (0), plus an unsorted list, which must get no table."""
+    L = nsbind.hip_lib()
+    ctx = C.c_void_p()
+    assert L.ns_ctx_create(0, C.byref(ctx)) == 0
+    try:
+        N = 7000
+        rng = np.random.default_rng(1024)
+        doc_len = np.full(N, 100, dtype=np.uint32)
+        avgdl = 100.0
+        all_docs = np.arange(N, dtype=np.uint32)
+        gaps = np.sort(rng.choice(N, size=5200, replace=False)).astype(np.uint32)
+        third = all_docs[(all_docs % 3) == 1]
+        sparse = np.sort(rng.choice(N, size=40, replace=False)).astype(np.uint32)
+        late = all_docs[all_docs >= 4100]                       # nothing in the first four grid cells
+        lists = [(all_docs, np.full(N, 2, np.uint32)), (gaps, np.full(len(gaps), 1, np.uint32)), (third, np.full(len(third), 3, np.uint32)),
+                 (sparse, np.full(len(sparse), 2, np.uint32)), (late, np.full(len(late), 1, np.uint32))]
+        payload = [np.stack([d, t], axis=1).astype(np.uint32).ravel() for d, t in lists]
+        unsorted = np.stack([all_docs[::-1][:3000], np.full(3000, 1, np.uint32)], axis=1).astype(np.uint32).ravel()
+        flat = np.concatenate(payload + [unsorted])
+        offs = np.cumsum([0] + [len(p) * 4 for p in payload + [unsorted]])[:-1]
+        seg = C.c_void_p()
+        assert L.ns_segment_upload(ctx, 0, N, C.c_float(avgdl), doc_len.ctypes.data, flat.ctypes.data, flat.nbytes, C.byref(seg)) == 0, L.ns_last_error(ctx)
+        if skips:
+            which = [0, 1, 2, 3, 4, 5] if skips == 2 else [0, 2, 5]
+            bo = np.array([offs[i] for i in which], dtype=np.uint64)
+            cn = np.array([(len(lists[i][0]) if i < 5 else 3000) for i in which], dtype=np.uint32)
+            assert L.ns_segment_build_skips(ctx, seg, bo.ctypes.data, cn.ctypes.data, len(which)) == 0, L.ns_last_error(ctx)
+            assert L.ns_segment_build_skips(ctx, seg, bo.ctypes.data, cn.ctypes.data, len(which)) == 0   # again: left as they are
+            bad = np.array([4], dtype=np.uint64)
+            assert L.ns_segment_build_skips(ctx, seg, bad.ctypes.data, cn.ctypes.data, 1) != 0          # not a multiple of 8
+        assert L.ns_set_tuning(ctx, variant, 0, split) == 0
+        idfs = [1.0, 1.0, 2.0, 5.0, 0.5]
+        queries = [[0, 1], [1, 0], [0, 2], [0, 1, 2], [2, 1, 0, 3], [0], [1, 2], [0, 4], [4, 1], [3, 0, 4], [0, 0]]
+        qd = np.zeros(len(queries), dtype=nsbind.QDESC_DTYPE)
+        refs = []
+        for qi, q in enumerate(queries):
+            qd[qi] = (len(refs), len(q))
+            for li in q:
+                refs.append((0, len(lists[li][0]), int(offs[li]), idfs[li], 1.0))
+        refs = np.array(refs, dtype=nsbind.TERM_DTYPE)
+        for use in ((1, 0) if skips else (1,)):
+            assert L.ns_ctx_use_skips(ctx, use) == 0
+            for k in (1, 3, 10, 100):
+                rc, hits, nhits, found = nsbind.search_batch_raw(ctx, qd, refs, k)
+                assert rc == 0, L.ns_last_error(ctx)
+                for qi, q in enumerate(queries):
+                    acc = _np_bm25(lists, q, [idfs[li] for li in q], [1.0] * len(q), doc_len, avgdl)
+                    assert int(found[qi]) == len(acc), (variant, split, skips, use, k, qi)
+                    keyed = sorted(acc.items(), key=lambda kv: (-float(kv[1]), kv[0]))[:k]
+                    n = int(nhits[qi])
+                    assert n == len(keyed)
+                    assert [int(d) for d in hits[qi, :n]["doc"]] == [d for d, _ in keyed], (variant, split, skips, use, k, qi)
+                    want_bits = np.array([v for _, v in keyed], dtype=np.float32).view(np.uint32)
+                    np.testing.assert_array_equal(hits[qi, :n]["score"].view(np.uint32), want_bits)
+        assert L.ns_segment_release(ctx, seg) == 0
+    finally:
+        L.ns_ctx_destroy(ctx)
+
+
 def test_full_batches_equal_oracle_and_reference_digests(index_factory):
     """BASELINE configs 2-5 at FULL size, EVERY query of every batch: tests/golden/fullsize.json holds, per block of
     1024 queries, SHA-256 digests of the whole batch's answers — `exact` from the oracle (found, nhits, every hit's
@@ -193,7 +258,12 @@ def test_full_batches_equal_oracle_and_reference_digests(index_factory):
             if "ties" in e:
                 bad = [b for b, (x, y) in enumerate(zip(dig["ties"], e["ties"])) if x != y]
                 assert not bad, f"{cfg}: blocks {bad[:8]} differ from the real reference's tie-invariant digests"
-            # the optional streams (packed blocks, impacts, both) must not change a byte either
+            # the skip tables reload() built (doc-tile groups on the skip grid) must not change a byte ...
+            eng.use_skips(False)
+            h2, n2, f2, _ = eng.search_batch(gen(Q), K, flags)
+            assert hits.tobytes() == h2.tobytes() and nhits.tobytes() == n2.tobytes() and found.tobytes() == f2.tobytes(), (cfg, "skips off")
+            eng.use_skips(True)
+            # ... nor the optional streams (packed blocks, impacts, both)
             eng.build_packed()
             for pk in (1, 2):
                 eng.use_packed(pk)
