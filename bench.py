@@ -399,6 +399,7 @@ def main():
                                  + f"; {args.depth} steps in flight per ctx" + ("" if args.no_overlap else ", alternating between two streams")) if elapsed else "kernel leg only (--kernel-only)",
                 "kernel_variant": args.variant,
                 "work_items": kinfo.n_items,
+                "index_side_data": "skip tables for lists of >= n_docs/512 postings (4 B per list and 1024-doc cell, built at reload from the uploaded postings); no impact / packed streams in this leg",
             },
             "roofline": {
                 "bound": "hbm",
