@@ -256,6 +256,16 @@ int ns_merge_rank_rows(ns_ctx* ctx, const void* d_hits, const void* d_nhits, con
 int ns_invert_forward(ns_ctx* ctx, const uint32_t* doc_term_counts, uint32_t n_docs, const uint32_t* pairs,
                       uint64_t n_pairs, uint32_t n_terms, uint32_t* df_out, void* postings_out, uint64_t* kept_out,
                       float* device_ms_out);
+/* The same inversion, with the result KEPT on the device as a segment's posting stream (build -> serve without the
+ * postings crossing PCIe twice): `seg` is an upload in progress — ns_segment_upload_begin(ctx, id, n_docs, avgdl, doc_len,
+ * n_pairs * 8, &seg) with nothing appended yet; the call inverts the forward pairs (doc_term_counts has the segment's
+ * n_docs entries), leaves the {docId, tf} lists in termId order in the segment (shorter than announced by the dropped
+ * pairs: *kept_out postings), and ns_segment_upload_end(ctx, seg) then publishes it.  df_out[n_terms] gives the
+ * caller the lexicon: list t starts at byte 8 * sum(df_out[0..t)) and holds df_out[t] postings.  postings_out (may be
+ * NULL) additionally receives the lists in host memory, e.g. to write the inverted files. */
+int ns_segment_upload_inverted(ns_ctx* ctx, ns_seg* seg, const uint32_t* doc_term_counts, const uint32_t* pairs,
+                               uint64_t n_pairs, uint32_t n_terms, uint32_t* df_out, void* postings_out,
+                               uint64_t* kept_out, float* device_ms_out);
 
 int  ns_set_tuning(ns_ctx* ctx, uint32_t variant, uint32_t min_items, uint32_t split_postings);
 

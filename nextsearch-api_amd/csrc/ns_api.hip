@@ -1742,9 +1742,11 @@ extern "C" int ns_search_batch(ns_ctx* ctx, const ns_query_desc* queries, const 
 
 // ------------------------------------------------------------------------------------------------
 // f3: forward.bin -> inverted lists (csrc/ns_invert.hip)
-extern "C" int ns_invert_forward(ns_ctx* ctx, const uint32_t* doc_term_counts, uint32_t n_docs, const uint32_t* pairs,
-                                 uint64_t n_pairs, uint32_t n_terms, uint32_t* df_out, void* postings_out, uint64_t* kept_out,
-                                 float* device_ms_out) {
+// `adopt` != nullptr: the inverted lists also become the posting stream of that segment (an upload in progress whose announced
+// payload is n_pairs postings) by a device-to-device copy; postings_out may then be NULL.
+static int invert_run(ns_ctx* ctx, const uint32_t* doc_term_counts, uint32_t n_docs, const uint32_t* pairs,
+                      uint64_t n_pairs, uint32_t n_terms, uint32_t* df_out, void* postings_out, uint64_t* kept_out,
+                      float* device_ms_out, ns_seg* adopt) {
     if (!ctx) return fail(nullptr, NS_E_INVAL, "ns_invert_forward: ctx is NULL");
     if ((n_docs && !doc_term_counts) || (n_pairs && !pairs) || (n_terms && !df_out) || !kept_out) return fail(ctx, NS_E_INVAL, "ns_invert_forward: null argument");
     if (n_pairs >= (1ull << 32) - kIvTile) return fail(ctx, NS_E_INVAL, "ns_invert_forward: %llu pairs; this build indexes pairs with 32 bits (split the segment)", (unsigned long long)n_pairs);
@@ -1756,7 +1758,7 @@ extern "C" int ns_invert_forward(ns_ctx* ctx, const uint32_t* doc_term_counts, u
     if (prefix[n_docs] != n_pairs) return fail(ctx, NS_E_INVAL, "ns_invert_forward: the per-document counts sum to %llu, not to n_pairs = %llu", (unsigned long long)prefix[n_docs], (unsigned long long)n_pairs);
     if (n_terms) std::memset(df_out, 0, (size_t)n_terms * 4);
     if (!n_pairs) return NS_OK;
-    if (!postings_out) return fail(ctx, NS_E_INVAL, "ns_invert_forward: postings_out is NULL");
+    if (!postings_out && !adopt) return fail(ctx, NS_E_INVAL, "ns_invert_forward: postings_out is NULL");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const uint32_t n = (uint32_t)n_pairs;
@@ -1832,7 +1834,16 @@ extern "C" int ns_invert_forward(ns_ctx* ctx, const uint32_t* doc_term_counts, u
             for (uint32_t t = 0; t < n_terms; t++) df_out[t] = (h_first[t] == 0xFFFFFFFFu) ? 0u : df_out[t] - h_first[t] + 1u;
             for (uint32_t t = 0; t < n_terms; t++) kept += df_out[t];
             *kept_out = kept;   // the dropped pairs carry the largest key: they sort behind every list
-            if (kept) chk(hipMemcpy(postings_out, d_vals[cur], (size_t)kept * 8, hipMemcpyDeviceToHost));
+            if (kept && postings_out) chk(hipMemcpy(postings_out, d_vals[cur], (size_t)kept * 8, hipMemcpyDeviceToHost));
+            if (adopt) {   // the lists stay on the device: they ARE the segment's posting stream
+                if (kept) chk(hipMemcpyAsync(adopt->d_postings, d_vals[cur], (size_t)kept * 8, hipMemcpyDeviceToDevice, st));
+                if (kept != adopt->n_postings) {   // dropped pairs: the stream is shorter than announced; move the padding
+                    chk(hipMemsetAsync((char*)adopt->d_postings + kept * 8, 0xFF, kPadPostings * 8, st));
+                    chk(hipMemsetAsync((char*)adopt->d_pnorm + kept * 4, 0, kPadPostings * 4, st));
+                }
+                chk(hipStreamSynchronize(st));
+                if (e == hipSuccess) { adopt->n_postings = kept; adopt->filled = kept * 8; }
+            }
             float ms = 0.0f;
             if (e == hipSuccess && hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess && device_ms_out) *device_ms_out = ms;
         }
@@ -1842,6 +1853,21 @@ extern "C" int ns_invert_forward(ns_ctx* ctx, const uint32_t* doc_term_counts, u
     if (ev1) (void)hipEventDestroy(ev1);
     if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? NS_E_NOMEM : NS_E_HIP, "ns_invert_forward: %s", hipGetErrorString(e));
     return NS_OK;
+}
+
+extern "C" int ns_invert_forward(ns_ctx* ctx, const uint32_t* doc_term_counts, uint32_t n_docs, const uint32_t* pairs,
+                                 uint64_t n_pairs, uint32_t n_terms, uint32_t* df_out, void* postings_out, uint64_t* kept_out,
+                                 float* device_ms_out) {
+    return invert_run(ctx, doc_term_counts, n_docs, pairs, n_pairs, n_terms, df_out, postings_out, kept_out, device_ms_out, nullptr);
+}
+
+extern "C" int ns_segment_upload_inverted(ns_ctx* ctx, ns_seg* seg, const uint32_t* doc_term_counts, const uint32_t* pairs,
+                                          uint64_t n_pairs, uint32_t n_terms, uint32_t* df_out, void* postings_out,
+                                          uint64_t* kept_out, float* device_ms_out) {
+    if (!ctx || !seg || seg->ctx != ctx || !seg->pending) return fail(ctx, NS_E_STATE, "ns_segment_upload_inverted: no upload in progress for this segment");
+    if (seg->filled != 0) return fail(ctx, NS_E_STATE, "ns_segment_upload_inverted: the segment already received %llu payload bytes", (unsigned long long)seg->filled);
+    if (seg->n_postings != n_pairs) return fail(ctx, NS_E_INVAL, "ns_segment_upload_inverted: %llu pairs, but ns_segment_upload_begin announced %llu postings", (unsigned long long)n_pairs, (unsigned long long)seg->n_postings);
+    return invert_run(ctx, doc_term_counts, seg->n_docs, pairs, n_pairs, n_terms, df_out, postings_out, kept_out, device_ms_out, seg);
 }
 
 // ------------------------------------------------------------------------------------------------

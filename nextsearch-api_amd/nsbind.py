@@ -56,7 +56,7 @@ HIP_SYMBOLS = [
     "ns_segment_upload", "ns_segment_release", "ns_segment_upload_begin", "ns_segment_upload_append", "ns_segment_upload_end", "ns_search_batch", "ns_batch_prepare",
     "ns_batch_bind_outputs", "ns_batch_run", "ns_batch_stream", "ns_batch_gap_ms", "ns_batch_sync", "ns_batch_fetch", "ns_batch_get_info",
     "ns_batch_destroy", "ns_set_tuning", "ns_segment_build_impacts", "ns_ctx_use_impacts", "ns_ctx_set_host_threads", "ns_ctx_set_overlap", "ns_segment_build_packed", "ns_ctx_use_packed", "ns_segment_build_skips", "ns_ctx_use_skips",
-    "ns_invert_forward", "ns_merge_rank_rows", "ns_sem_upload", "ns_sem_release", "ns_sem_topk",
+    "ns_invert_forward", "ns_segment_upload_inverted", "ns_merge_rank_rows", "ns_sem_upload", "ns_sem_release", "ns_sem_topk",
 ]
 HOST_SYMBOLS = [
     "nsh_gen_index", "nsh_engine_open", "nsh_engine_close", "nsh_engine_reload", "nsh_engine_error", "nsh_engine_ctx",
@@ -106,6 +106,7 @@ def hip_lib():
         L.ns_sem_topk.argtypes = [vp, vp, vp, u32, u32, C.c_float, vp, vp, vp, vp, vp, vp]
         L.ns_merge_rank_rows.argtypes = [vp, vp, vp, vp, u32, u32, u32, vp, u32, vp, vp, vp]
         L.ns_invert_forward.argtypes = [vp, vp, u32, vp, u64, u32, vp, vp, C.POINTER(u64), vp]
+        L.ns_segment_upload_inverted.argtypes = [vp, vp, vp, vp, u64, u32, vp, vp, C.POINTER(u64), vp]
         L.ns_search_batch.argtypes = [vp, vp, vp, u32, u32, vp, vp, vp, u32]
         L.ns_batch_prepare.argtypes = [vp, vp, vp, u32, u32, u32, C.POINTER(vp)]
         L.ns_batch_bind_outputs.argtypes = [vp, vp, vp, vp]

@@ -151,3 +151,63 @@ def test_inverted_segment_serves_the_hot_path(tmp_path):
     for t in np.nonzero(df)[0][:50]:
         lst = got[starts[t]:starts[t + 1]]
         assert np.all(np.diff(lst[:, 0].astype(np.int64)) > 0)
+
+
+@pytest.mark.gpu
+def test_inverted_lists_stay_on_the_device_as_a_segment(tmp_path):
+    """ns_segment_upload_inverted: the inversion's result becomes a segment's posting stream without leaving the device.
+    The segment must serve exactly what a segment uploaded from the oracle's inverted lists serves (hits, nhits, found:
+    bytes), its df_out must be the oracle's, dropped termIds shorten the stream, and the state machine refuses misuse."""
+    L = nsbind.hip_lib()
+    seg = tmp_path / "seg"
+    forward_gen.write_inputs(str(seg), 6000, 700, 30, 23, bad_ids=True)      # some termIds >= n_terms: dropped
+    counts, pairs = invert_oracle.read_forward(str(seg / "forward.bin"))
+    counts = np.ascontiguousarray(counts, dtype=np.uint32)
+    pairs = np.ascontiguousarray(pairs, dtype=np.uint32)
+    n_docs, n_pairs, n_terms = len(counts), len(pairs), 700
+    df, postings = invert_oracle.invert(counts, pairs, n_terms)
+    postings = np.ascontiguousarray(postings, dtype=np.uint32)
+    assert 0 < len(postings) < n_pairs
+    doc_len = np.maximum(1, np.bincount(np.repeat(np.arange(n_docs), counts), weights=pairs[:, 1], minlength=n_docs)).astype(np.uint32)
+    avgdl = float(np.float32(doc_len.astype(np.float64).mean()))
+    ctx = C.c_void_p()
+    assert L.ns_ctx_create(0, C.byref(ctx)) == 0
+    try:
+        # reference segment: the oracle's lists through the ordinary upload
+        s_ref = C.c_void_p()
+        assert L.ns_segment_upload(ctx, 0, n_docs, C.c_float(avgdl), doc_len.ctypes.data, postings.ctypes.data, postings.nbytes, C.byref(s_ref)) == 0
+        # device hand-over
+        s_dev = C.c_void_p()
+        assert L.ns_segment_upload_begin(ctx, 1, n_docs, C.c_float(avgdl), doc_len.ctypes.data, n_pairs * 8, C.byref(s_dev)) == 0
+        df_out = np.zeros(n_terms, dtype=np.uint32)
+        host_copy = np.zeros((n_pairs, 2), dtype=np.uint32)
+        kept = C.c_uint64()
+        assert L.ns_segment_upload_inverted(ctx, s_dev, counts.ctypes.data, pairs.ctypes.data, n_pairs + 1, n_terms, df_out.ctypes.data, None, C.byref(kept), None) != 0
+        assert L.ns_segment_upload_inverted(ctx, s_dev, counts.ctypes.data, pairs.ctypes.data, n_pairs, n_terms, df_out.ctypes.data,
+                                            host_copy.ctypes.data, C.byref(kept), None) == 0, L.ns_last_error(ctx)
+        assert kept.value == len(postings) and np.array_equal(df_out, df.astype(np.uint32)) and np.array_equal(host_copy[:kept.value], postings)
+        assert L.ns_segment_upload_inverted(ctx, s_dev, counts.ctypes.data, pairs.ctypes.data, n_pairs, n_terms, df_out.ctypes.data, None, C.byref(kept), None) != 0   # already filled
+        assert L.ns_segment_upload_end(ctx, s_dev) == 0, L.ns_last_error(ctx)
+        assert L.ns_segment_upload_inverted(ctx, s_dev, counts.ctypes.data, pairs.ctypes.data, n_pairs, n_terms, df_out.ctypes.data, None, C.byref(kept), None) != 0   # published
+        starts = np.concatenate([[0], np.cumsum(df, dtype=np.int64)])
+        order = np.argsort(-df.astype(np.int64), kind="stable")
+        rng = np.random.default_rng(3)
+        queries = [[int(order[0]), int(order[1])], [int(order[2])], [int(order[0]), int(order[5]), int(order[300])]]
+        queries += [[int(t) for t in rng.choice(np.nonzero(df)[0], size=rng.integers(1, 6), replace=False)] for _ in range(60)]
+        res = []
+        for sid in (0, 1):
+            qd = np.zeros(len(queries), dtype=nsbind.QDESC_DTYPE)
+            refs = []
+            for qi, q in enumerate(queries):
+                qd[qi] = (len(refs), len(q))
+                for t in q:
+                    refs.append((sid, int(df[t]), int(starts[t]) * 8, 1.0 + (t % 7) * 0.25, 1.0))
+            refs = np.array(refs, dtype=nsbind.TERM_DTYPE)
+            for k in (10, 100):
+                rc, hits, nhits, found = nsbind.search_batch_raw(ctx, qd, refs, k)
+                assert rc == 0, L.ns_last_error(ctx)
+                res.append((hits["score"].tobytes(), hits["doc"].tobytes(), nhits.tobytes(), found.tobytes()))
+        assert res[0] == res[2] and res[1] == res[3]
+        assert int(np.frombuffer(res[0][3], dtype=np.uint64).sum()) > 0
+    finally:
+        L.ns_ctx_destroy(ctx)

@@ -58,6 +58,35 @@ def main():
                        for f in ["barrels.bin"] + ["inverted_b%03u.bin" % b for b in range(64)] + ["lexicon_b%03u.bin" % b for b in range(64)])
             cpu = {"value": pairs / dt, "unit": "pairs/s", "cores": 1, "kind": kind, "seconds": dt,
                    "sample": "the same forward.bin, files in -> files out", "identical_files": same}
+        # build -> serve: the inverted lists handed to a segment on the device (ns_segment_upload_inverted) against the
+        # round trip (lists to the host, then an ordinary ns_segment_upload of them)
+        import ctypes as C
+        import numpy as np
+        import invert_oracle
+        counts, prs = invert_oracle.read_forward(os.path.join(seg, "forward.bin"))
+        counts = np.ascontiguousarray(counts, dtype=np.uint32); prs = np.ascontiguousarray(prs, dtype=np.uint32)
+        doc_len = np.ones(len(counts), dtype=np.uint32)
+        L = nsbind.hip_lib()
+        ctx = C.c_void_p()
+        assert L.ns_ctx_create(0, C.byref(ctx)) == 0
+        df = np.zeros(args.terms, dtype=np.uint32); kept = C.c_uint64(); out = np.zeros((len(prs), 2), dtype=np.uint32)
+        hand, trip = [], []
+        for rep in range(args.reps + 1):      # each way in a loop of its own: hipFree defers work to the next allocation
+            sg = C.c_void_p()
+            t0 = time.perf_counter()
+            assert L.ns_segment_upload_begin(ctx, 0, len(counts), C.c_float(1.0), doc_len.ctypes.data, len(prs) * 8, C.byref(sg)) == 0
+            assert L.ns_segment_upload_inverted(ctx, sg, counts.ctypes.data, prs.ctypes.data, len(prs), args.terms, df.ctypes.data, None, C.byref(kept), None) == 0
+            assert L.ns_segment_upload_end(ctx, sg) == 0
+            hand.append(time.perf_counter() - t0)
+            assert L.ns_segment_release(ctx, sg) == 0
+        for rep in range(args.reps + 1):
+            sg = C.c_void_p()
+            t0 = time.perf_counter()
+            assert L.ns_invert_forward(ctx, counts.ctypes.data, len(counts), prs.ctypes.data, len(prs), args.terms, df.ctypes.data, out.ctypes.data, C.byref(kept), None) == 0
+            assert L.ns_segment_upload(ctx, 0, len(counts), C.c_float(1.0), doc_len.ctypes.data, out.ctypes.data, kept.value * 8, C.byref(sg)) == 0
+            trip.append(time.perf_counter() - t0)
+            assert L.ns_segment_release(ctx, sg) == 0
+        L.ns_ctx_destroy(ctx)
         gbs = 16.0 * pairs / (best["device_ms"] * 1e-3) / 1e9
         print(json.dumps({
             "metric": "index inversion, (termId, tf) pairs per second (device part)", "value": pairs / (best["device_ms"] * 1e-3),
@@ -65,6 +94,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
                          "algo_bytes": 16 * pairs},
             "host_inclusive": {"ns_invert_forward_s": best["call_s"], "files_in_to_files_out_s": best["total_s"]},
+            "build_to_serve": {"handed_over_on_device_s": min(hand[1:]), "via_host_round_trip_s": min(trip[1:]),
+                               "what": "forward pairs in host memory -> a searchable segment (posting stream + norms on the device)"},
             "cpu_baseline": cpu}), flush=True)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
