@@ -232,6 +232,21 @@ def test_equal_scores_in_doc_tiles_and_skip_tables(variant, split, skips):
                     assert [int(d) for d in hits[qi, :n]["doc"]] == [d for d, _ in keyed], (variant, split, skips, use, k, qi)
                     want_bits = np.array([v for _, v in keyed], dtype=np.float32).view(np.uint32)
                     np.testing.assert_array_equal(hits[qi, :n]["score"].view(np.uint32), want_bits)
+            # the conjunctive extension over the same groups: a doc counts when EVERY term ref of the query holds it
+            for k in (3, 100):
+                rc, hits, nhits, found = nsbind.search_batch_raw(ctx, qd, refs, k, nsbind.NS_FLAG_AND)
+                assert rc == 0, L.ns_last_error(ctx)
+                for qi, q in enumerate(queries):
+                    acc = _np_bm25(lists, q, [idfs[li] for li in q], [1.0] * len(q), doc_len, avgdl)
+                    members = set(lists[q[0]][0].tolist())
+                    for li in q[1:]:
+                        members &= set(lists[li][0].tolist())
+                    keyed = sorted(((d, v) for d, v in acc.items() if d in members), key=lambda kv: (-float(kv[1]), kv[0]))
+                    assert int(found[qi]) == len(keyed), (variant, split, skips, use, k, qi, "AND")
+                    n = int(nhits[qi])
+                    assert n == min(k, len(keyed))
+                    assert [int(d) for d in hits[qi, :n]["doc"]] == [d for d, _ in keyed[:k]], (variant, split, skips, use, k, qi, "AND")
+                    np.testing.assert_array_equal(hits[qi, :n]["score"].view(np.uint32), np.array([v for _, v in keyed[:k]], dtype=np.float32).view(np.uint32))
         assert L.ns_segment_release(ctx, seg) == 0
     finally:
         L.ns_ctx_destroy(ctx)
