@@ -2015,7 +2015,7 @@ extern "C" int ns_debug_counters(unsigned long long* out, int reset) {
     return 0;
 }
 extern "C" int ns_debug_tile_counters(unsigned long long* out, int reset) {
-    unsigned long long h[8];
+    unsigned long long h[12];
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(ns::g_ns_tcnt), sizeof(h)) != hipSuccess) return -1;
     if (out) std::memcpy(out, h, sizeof(h));

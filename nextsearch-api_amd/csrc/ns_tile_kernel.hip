@@ -23,7 +23,7 @@
 namespace ns {
 
 #ifdef NS_COUNT
-__device__ unsigned long long g_ns_tcnt[8];   // diagnostic build: event counts of the doc-tile body (tools/dbg/count_run.py)
+__device__ unsigned long long g_ns_tcnt[12];   // diagnostic build: event counts of the doc-tile body (tools/dbg/count_run.py)
 #endif
 
 template <int TD, bool AND, int CB = 256, bool IMP = false>
@@ -99,9 +99,10 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
     uint32_t nsorted = 0;   // leading candidates already in descending order (left by the last shrink)
     uint32_t found_s = 0;   // wave-uniform count (popcounts of ballots)
 #ifdef NS_COUNT
-    unsigned long long tc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define NS_TCNT(i, v) tc_[(i)] += (unsigned long long)(v)
     NS_TCNT(0, 1);
+    const unsigned long long tc_t0_ = __builtin_readcyclecounter();
 #else
 #define NS_TCNT(i, v)
 #endif
@@ -178,7 +179,15 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
                     // games, no per-chunk branches: the arithmetic of the general round below with every lane live.
                     // (Measured next to it: ALL rounds of such a term as straight-line code, lanes past the segment's end
                     // parked on dummy slots — fewer instructions, but slower on mixed batches; profiles/r02/ab.)
+#ifdef NS_COUNT
+                    const unsigned long long tr0_ = __builtin_readcyclecounter();
+#endif
                     NS_ISSUE(ps, nr, s_cur, (uint32_t)(E * 64));
+#ifdef NS_COUNT
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const unsigned long long tr1_ = __builtin_readcyclecounter();
+                    NS_TCNT(8, tr1_ - tr0_); NS_TCNT(9, 1);
+#endif
                     NS_TCNT(3, 1); NS_TCNT(4, E); NS_TCNT(5, E * 64);
                     float xq[E], oldq[E];
                     uint32_t slq[E];
@@ -212,6 +221,10 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
                         if (AND) mcnt[slq[j]] = (uint8_t)(mcnt[slq[j]] + 1);
                     }
                     s_cur += (uint32_t)(E * 64);
+#ifdef NS_COUNT
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    NS_TCNT(11, __builtin_readcyclecounter() - tr0_);
+#endif
                     continue;
                 }
                 uint32_t n;
@@ -333,6 +346,9 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
 
         // ---- read the tile back: candidates, reset (and, for the conjunctive extension, found) ----
         bool ge_mode = false;   // after a shrink INSIDE this tile, ties with theta may still win on docId
+#ifdef NS_COUNT
+        const unsigned long long trb0_ = __builtin_readcyclecounter();
+#endif
         if (touched) {
 #pragma unroll
         for (int g = 0; g < NG; g++) {
@@ -380,6 +396,9 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
         }
         wave_sync();
         if (ncand > (uint32_t)(CB - 64)) ncand = wave_shrink_cb<CB>(cand, ncand, nsorted, theta, K, lane);   // keep room for one more step of offers
+#ifdef NS_COUNT
+        NS_TCNT(10, __builtin_readcyclecounter() - trb0_);
+#endif
     }
 #undef NS_ISSUE
 #undef NS_ROUND_SIZE
@@ -410,8 +429,9 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
     }
 #ifdef NS_COUNT
     NS_TCNT(6, T);
+    NS_TCNT(7, __builtin_readcyclecounter() - tc_t0_);
     if (lane == 0)
-        for (int i = 0; i < 8; i++) if (tc_[i]) atomicAdd(&g_ns_tcnt[i], tc_[i]);
+        for (int i = 0; i < 12; i++) if (tc_[i]) atomicAdd(&g_ns_tcnt[i], tc_[i]);
 #endif
 #undef NS_TCNT
 }

@@ -22,7 +22,7 @@ for n in (sys.argv[1] if len(sys.argv) > 1 else "cfg5_gen").split(","):
     qs, k = laws[n]
     b = eng.prepare(qs, k)
     out = (C.c_uint64 * 16)()
-    tout = (C.c_uint64 * 8)()
+    tout = (C.c_uint64 * 12)()
     L.ns_debug_counters(out, 1); L.ns_debug_tile_counters(tout, 1)
     b.run(True); b.sync()
     L.ns_debug_counters(out, 1); L.ns_debug_tile_counters(tout, 1)
@@ -38,4 +38,7 @@ for n in (sys.argv[1] if len(sys.argv) > 1 else "cfg5_gen").split(","):
         t = max(tout[1], 1)
         print(f"    doc-tile body: items {tout[0]}, tiles {tout[1]}, (term, tile) visits {tout[2]} ({tout[2] / t:.2f} per tile), rounds {tout[3]} ({tout[3] / max(tout[2], 1):.2f} per visit), "
               f"chunks loaded {tout[4]} ({tout[4] / t:.2f} per tile), postings taken {tout[5]} ({tout[5] / t:.1f} per tile; lanes used {tout[5] / max(tout[4] * 64, 1):.3f}), terms per item {tout[6] / tout[0]:.2f}")
+        if tout[9]:
+            print(f"    doc-tile body, shader clocks: item {tout[7] / tout[0]:.0f} per item ({tout[7] / max(tout[5], 1) * 64:.0f} per 64 postings); full rounds {tout[9]}: "
+                  f"issue -> data {tout[8] / tout[9]:.0f}, whole round {tout[11] / tout[9]:.0f}; tile read-back (+ shrink) {tout[10] / t:.0f} per tile")
     b.close()
