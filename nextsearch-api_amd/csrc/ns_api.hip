@@ -1146,16 +1146,6 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                     // work estimate in units of one streamed driver posting (measured, profiles/r01): a foreign
                     // posting (claim, accumulate, read back) costs ~8x, a doc-tile posting ~2x
                     hg.work = !auto_mode ? hg.cost : (hg.cls == 2 ? hg.cost * kWorkTile : hg.cmax + rest * kWorkForeign);
-                    // doc-tile groups walk the skip grid when some list of theirs has a skip table (ns_segment_build_skips)
-                    if (auto_mode && hg.cls == 2 && hg.wave && ctx->use_skips && !ctx->segs[sid]->skip_tab.empty()) {
-                        const ns_seg* sg_ = ctx->segs[sid];
-                        for (uint32_t ti = hg.g.term_begin; ti < (uint32_t)S.dterms.size(); ti++) {
-                            DevTerm& dt = S.dterms[ti];
-                            if (dt.count < kSkipMinCount) continue;
-                            dt.skip = sg_->skip_of((uint32_t)dt.list_off, dt.count);
-                            if (dt.skip) hg.grid = true;
-                        }
-                    }
                 }
                 if (!hg.wave) {
                     hg.g.bounds_off = S.bounds_total;   // local; the slice's base is added in phase B
@@ -1241,6 +1231,19 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                         if (!small_mode && (uint64_t)ns * ns * 2 < (uint64_t)p2 * p2) p2 >>= 1;   // a batch that leaves wave slots idle never gets fewer items
                         ns = std::min<uint32_t>(p2, std::min<uint32_t>(sg.n_docs, 4096));
                     }
+                    // Skip tables (ns_segment_build_skips): a doc-tile group walks the grid of its lists' tables; a group of the
+                    // driver-stream bodies that is cut into ranges takes the ranges' ends of its frequent lists from their
+                    // tables instead of searching for them (the searches of a hot list are a dozen dependent loads: 4-20 % of
+                    // an item's time, most in small batches).  Either way the ranges start and end on the grid.
+                    if (auto_mode && ctx->use_skips && (hg.cls == 2 || ns > 1) && !ctx->segs[hg.g.seg]->skip_tab.empty()) {
+                        const ns_seg* sg_ = ctx->segs[hg.g.seg];
+                        DevTerm* dt = S.dterms.data() + (hg.g.term_begin - S.term_off);
+                        for (uint32_t ti = 0; ti < hg.g.term_count; ti++) {
+                            if (dt[ti].count < kSkipMinCount) continue;
+                            dt[ti].skip = sg_->skip_of((uint32_t)dt[ti].list_off, dt[ti].count);
+                            if (dt[ti].skip) hg.grid = true;
+                        }
+                    }
                     // launch-order key = estimated run time of the ITEM: its share of the group's work plus what
                     // every item pays per term regardless of size (window planning, range searches, table set-up)
                     const uint64_t per_term = hg.cls == 2 ? kItemTermTile : (hg.cls == 1 ? kItemTermThin : kItemTermGeneral);
@@ -1261,7 +1264,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                         }
                         if (it.doc_hi <= it.doc_lo) continue;
                         it.out_slot = S.n_rows++;
-                        it.whole = (ns == 1 ? 1u : 0u) | (hg.fast_div ? 8u : 0u) | (hg.signed_in ? 16u : 0u) | (hg.grid ? 32u : 0u);
+                        it.whole = (ns == 1 ? 1u : 0u) | (hg.fast_div ? 8u : 0u) | (hg.signed_in ? 16u : 0u) | (hg.grid ? (hg.cls == 2 ? 32u : 64u) : 0u);
                         // auto mode: very dense groups take the doc-tile body (bit 1), groups with thin non-driver lists the small foreign budget (bit 2)
                         if (auto_mode) it.whole |= (hg.cls == 2 ? 2u : 0u) | (hg.cls == 1 ? 4u : 0u);
                         S.witems.push_back(it);
@@ -2018,7 +2021,7 @@ extern "C" int ns_sem_topk(ns_ctx* ctx, ns_sem* sem, const float* qvecs, uint32_
 #ifdef NS_COUNT
 // Diagnostic build only: the driver-stream body's event counters (ns_driver_kernel.hip), optionally reset.
 extern "C" int ns_debug_counters(unsigned long long* out, int reset) {
-    unsigned long long h[16];
+    unsigned long long h[20];
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(ns::g_ns_cnt), sizeof(h)) != hipSuccess) return -1;
     if (out) std::memcpy(out, h, sizeof(h));

@@ -32,7 +32,7 @@ namespace ns {
 #ifdef NS_COUNT
 // Diagnostic build only (make -C nextsearch-api_amd count): event counts of the driver-stream body, summed over all
 // items of all launches since the last reset; read through ns_debug_counters (tools/dbg/count_run.py).
-__device__ unsigned long long g_ns_cnt[16];
+__device__ unsigned long long g_ns_cnt[20];
 #define NS_CNT(i, v) cnt_[(i)] += (unsigned long long)(v)
 #else
 #define NS_CNT(i, v)
@@ -132,6 +132,9 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
     static_assert(FB % 64 == 0 && FB >= 64 && FB <= 256 && FB <= 2 * NB, "FB must be a multiple of 64, at most 256 and 2*NB");
     uint4* ent4 = reinterpret_cast<uint4*>(ent);
 
+#ifdef NS_COUNT
+    const unsigned long long cyc_t0_ = __builtin_readcyclecounter();
+#endif
     const DevSeg seg = segs[it.seg];
     const uint32_t T = it.term_count;
     const bool fast_div = (__builtin_amdgcn_readfirstlane((int)it.whole) & 8) != 0;   // host: every idf and norm of this item is in the range where v_div_scale/v_div_fixup are the identity
@@ -162,8 +165,15 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
         wq_bits = __float_as_uint(tm.weight);
         end = tm.count;
         if (!(it.whole & 1u)) {
-            const uint2* lst = seg.postings + tm.list_off;
-            list_range(lst, tm.count, it.doc_lo, it.doc_hi, seg.n_docs, cur, end);
+            if ((it.whole & 64u) && tm.skip != 0u) {
+                // the range's ends come from the list's skip table (the host put doc_lo, and doc_hi unless it is n_docs, on the grid)
+                const gp_u32 sk = (gp_u32)seg.skips + (tm.skip - 1u);
+                cur = sk[it.doc_lo / kSkipDocs] - base;
+                end = sk[(it.doc_hi + (kSkipDocs - 1u)) / kSkipDocs] - base;
+            } else {
+                const uint2* lst = seg.postings + tm.list_off;
+                list_range(lst, tm.count, it.doc_lo, it.doc_hi, seg.n_docs, cur, end);
+            }
             if (end < cur) end = cur;
         }
         cur += base;   // absolute posting indices from here on
@@ -194,7 +204,8 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
     if ((uint32_t)lane == dl) { cur = end; }   // the driver is streamed through d_cur, not through its lane
 
 #ifdef NS_COUNT
-    unsigned long long cnt_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long cnt_[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    cnt_[16] = __builtin_readcyclecounter() - cyc_t0_; cnt_[17] = 0;
     NS_CNT(0, 1);
     NS_CNT(10, T);
 #endif
@@ -690,6 +701,9 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
 #undef NS_TAG
 #undef NS_IDENT
 
+#ifdef NS_COUNT
+    const unsigned long long cyc_t1_ = __builtin_readcyclecounter();
+#endif
     // ---- this item's top-K ----
     wave_sync();
     ncand = wave_shrink_cb<CB>(cand, ncand, nsorted, theta, K, lane);
@@ -721,8 +735,10 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
         out_found[it.out_slot] = (uint64_t)found + (uint64_t)found_s;
     }
 #ifdef NS_COUNT
+    cnt_[17] = __builtin_readcyclecounter() - cyc_t0_;
+    cnt_[18] = __builtin_readcyclecounter() - cyc_t1_;
     if (lane == 0)
-        for (int i = 0; i < 16; i++) if (cnt_[i]) atomicAdd(&g_ns_cnt[i], cnt_[i]);
+        for (int i = 0; i < 20; i++) if (cnt_[i]) atomicAdd(&g_ns_cnt[i], cnt_[i]);
 #endif
 }
 

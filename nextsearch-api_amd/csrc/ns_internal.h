@@ -90,6 +90,8 @@ struct DevWItem {
                            //        driver stream then canonicalises its private scores as the reference's 0.0f + x does)
                            // bit 5: doc-tile body on the skip grid: doc_lo is a multiple of kSkipDocs, tiles are grid cells,
                            //        and the terms with DevTerm::skip != 0 take their postings of a tile from the skip table
+                           // bit 6: driver-stream bodies: doc_lo (and doc_hi, unless it is n_docs) are multiples of kSkipDocs, and the
+                           //        terms with DevTerm::skip != 0 take the range's ends in their lists from the skip table
 };
 
 // Term group == the (query, segment) unit the boundary prepass works on.

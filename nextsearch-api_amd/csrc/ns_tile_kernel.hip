@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(64 * kUscoreWavesPerBlock) __attribute__((amdg
     DevWItem it = items[item_idx];
     const bool tiles = (it.whole & 2u) != 0;
     const bool thin = (it.whole & 4u) != 0;   // the non-driver lists are thin: smallest foreign budget
-    it.whole &= 57u;   // bit 0: whole segment, bit 3: short division, bit 4: signed inputs, bit 5: skip grid (doc tiles)
+    it.whole &= 121u;   // bit 0: whole segment, bit 3: short division, bit 4: signed inputs, bits 5 / 6: skip grid (doc tiles / range ends)
     if (thin)
         dscore_body<HK / 2, 64, AND, CB, IMP, PK>(it, terms, segs, s_tbl[wave], s_vals[wave], s_mcnt[wave], s_cand[wave],
                                  s_tab[wave], s_aux[wave], out_hits, out_nhits, out_found, K, lane);

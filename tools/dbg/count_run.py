@@ -21,7 +21,7 @@ names = ["items (driver-stream body)", "super-batches", "super-batches with fore
 for n in (sys.argv[1] if len(sys.argv) > 1 else "cfg5_gen").split(","):
     qs, k = laws[n]
     b = eng.prepare(qs, k)
-    out = (C.c_uint64 * 16)()
+    out = (C.c_uint64 * 20)()
     tout = (C.c_uint64 * 12)()
     L.ns_debug_counters(out, 1); L.ns_debug_tile_counters(tout, 1)
     b.run(True); b.sync()
@@ -34,6 +34,8 @@ for n in (sys.argv[1] if len(sys.argv) > 1 else "cfg5_gen").split(","):
     print(f"    foreign window utilisation {out[4] / max(out[3], 1):.3f}; lanes used in foreign chunks {out[4] / max(out[5] * 64, 1):.3f}; "
           f"driver round utilisation {out[9] / max(out[8] * 256, 1):.3f}; lanes used in driver chunks {out[9] / max(out[12] * 64, 1):.3f}; "
           f"foreign share of consumed postings {out[4] / max(out[4] + out[9], 1):.3f}")
+    if out[0] and out[17]:
+        print(f"    driver-stream body, shader clocks per item: whole {out[17] / out[0]:.0f}, set-up (term table, range searches, first window plan) {out[16] / out[0]:.0f}, final shrink + rows out {out[18] / out[0]:.0f}")
     if tout[0]:
         t = max(tout[1], 1)
         print(f"    doc-tile body: items {tout[0]}, tiles {tout[1]}, (term, tile) visits {tout[2]} ({tout[2] / t:.2f} per tile), rounds {tout[3]} ({tout[3] / max(tout[2], 1):.2f} per visit), "
