@@ -34,7 +34,6 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
     // CB: candidate buffer entries, a power of two >= K + 64
     constexpr int E = 4;                   // postings per lane per round
     constexpr int NG = TD / 256;           // float4 groups per lane in the tile read-back
-    constexpr bool kPrefetch = false;      // next-round prefetch: measured slower (more registers, the body is VALU-bound)
     static_assert(TD == 512 || TD == 1024 || TD == 2048, "TD must be 512, 1024 or 2048");
 
     const DevSeg seg = segs[it.seg];
@@ -109,13 +108,11 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
     wave_sync();
 
     // One round = up to E*64 postings of one term, loaded with a scalar base + a fixed lane offset (lanes
-    // past n read the next list or the buffer's padding and are masked).  The round that is expected to
-    // come next — the same term's next E*64 postings, the next term of the tile, or the first term of the
-    // next tile — is loaded into a second register set BEFORE the current round is processed, so its HBM
-    // latency overlaps the BM25 arithmetic, the LDS read-add-writes and the tile read-back.
-    nat_u2 ps[E], pn[E];
-    float nr[E], nn[E];
-    uint32_t pf_start = 0xFFFFFFFFu, pf_n = 0;   // the prefetched round: absolute posting index of its first posting, size
+    // past n read the next list or the buffer's padding and are masked).  One round is in flight per wave: loading the
+    // round expected next into a second register set, or into the same registers once they are dead, was measured slower
+    // (fewer waves; the compiler waits for loop-carried loads at the back-edge — DESIGN §5, ab4 / ab11).
+    nat_u2 ps[E];
+    float nr[E];
 #define NS_ISSUE(PS, NR, start, nn_)                                                               \
     {                                                                                              \
         const gp_u2 sp_ = stream + (start);                                                        \
@@ -128,7 +125,7 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
     }
 #define NS_ROUND_SIZE(rem_, want_) min(min((rem_), (uint32_t)(E * 64)), max((want_), 64u))
 #pragma unroll
-    for (int j = 0; j < E; j++) { ps[j] = nat_u2{0xFFFFFFFFu, 0u}; pn[j] = nat_u2{0xFFFFFFFFu, 0u}; nr[j] = 1.0f; nn[j] = 1.0f; }
+    for (int j = 0; j < E; j++) { ps[j] = nat_u2{0xFFFFFFFFu, 0u}; nr[j] = 1.0f; }
 
     // ---- tile header: the next tile starts at the first doc that still has a posting (empty doc space costs nothing) ----
     uint32_t lo = it.doc_lo, hi = 0;
@@ -227,33 +224,12 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
 #endif
                     continue;
                 }
-                uint32_t n;
-                if (kPrefetch && pf_start == s_cur) {   // the prefetched round is this one
-                    n = pf_n;
-#pragma unroll
-                    for (int j = 0; j < E; j++) { ps[j] = pn[j]; nr[j] = nn[j]; }
-                } else {
-                    n = NS_ROUND_SIZE(remd, want);
-                    NS_ISSUE(ps, nr, s_cur, n);
-                }
+                const uint32_t n = NS_ROUND_SIZE(remd, want);
+                NS_ISSUE(ps, nr, s_cur, n);
                 NS_TCNT(3, 1);                       // rounds
                 NS_TCNT(4, (n + 63) / 64);           // chunks loaded
                 const bool expect_more = want > n;
                 if (!exact) want = expect_more ? (want - n) : 64u;   // exact: every round is as large as what is left allows
-                // ---- prefetch the round expected next ----
-                pf_start = 0xFFFFFFFFu;
-                if (!kPrefetch) {
-                } else if (expect_more && s_cur + n < s_end) {
-                    pf_start = s_cur + n;
-                    pf_n = NS_ROUND_SIZE(s_end - pf_start, want);
-                } else if (act != 0ull) {
-                    const uint32_t t2 = (uint32_t)__builtin_ctzll(act);
-                    pf_start = rdlane(cur, t2);
-                    const uint32_t rem2 = rdlane(end, t2) - pf_start;   // > 0: an active term has a posting at its cursor
-                    pf_n = NS_ROUND_SIZE(rem2, 16u + (uint32_t)((float)rem2 * frac * 1.125f));
-                }
-                if (pf_start != 0xFFFFFFFFu) NS_ISSUE(pn, nn, pf_start, pf_n);
-
                 uint32_t cnt = 0;
                 uint64_t takem[E];
                 float x[E];
@@ -320,7 +296,7 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
             wave_sync();   // the next term's read-add-writes follow this term's
         }
 
-        // ---- header of the NEXT tile, and the first round of its first term goes out before the read-back ----
+        // ---- header of the NEXT tile (its skip entries were read one tile ago) ----
         if (tile_hi >= last_doc) { done = true; }
         else {
             lo = tile_hi + 1u;
@@ -332,16 +308,6 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
                 }
             }
             NS_TILE_HEADER();
-            if (kPrefetch && !done && act != 0ull) {
-                const uint32_t t0 = (uint32_t)__builtin_ctzll(act);
-                const uint32_t st0 = rdlane(cur, t0);
-                if (pf_start != st0) {
-                    const uint32_t rem0 = rdlane(end, t0) - st0;
-                    pf_start = st0;
-                    pf_n = NS_ROUND_SIZE(rem0, 16u + (uint32_t)((float)rem0 * frac * 1.125f));
-                    NS_ISSUE(pn, nn, pf_start, pf_n);
-                }
-            }
         }
 
         // ---- read the tile back: candidates, reset (and, for the conjunctive extension, found) ----
