@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised differential test of the HIP path against the CPU oracle (test infrastructure; GPU box only):
-random index shapes, query laws, K, OR/AND, work-splitting knobs, with and without impact streams.
+random index shapes, query laws, K, OR/AND, work-splitting knobs, with and without impact streams, packed streams and skip tables.
 Stops at the first mismatch and prints the case; prints a summary line otherwise."""
 import argparse
 import os
@@ -90,10 +90,12 @@ def _run(rng, t0, last, cases, tmp, seconds, max_cases, verbose):
                 if pk:
                     eng.build_packed()
                 eng.use_packed(pk)
+                skips = rng.random() < 0.75     # reload() builds skip tables for the frequent lists; searches may ignore them
+                eng.use_skips(skips)
                 bad = same(eng.search_batch(qs, k, flags), ora.search_batch(qs, k, flags, threads=8))
                 if bad:
                     return cases, (f"MISMATCH {bad}: index(nseg={nseg}, docs={docs}, vocab={vocab}, seed={seed}) law={law} nq={nq} k={k} "
-                                   f"flags={flags} tune={tune} impacts={imp} packed={pk} queries={qs[:5]}")
+                                   f"flags={flags} tune={tune} impacts={imp} packed={pk} skips={skips} queries={qs[:5]}")
                 cases += 1
                 if verbose and time.time() - last > 30:
                     last = time.time()
