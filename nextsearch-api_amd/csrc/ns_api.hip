@@ -1254,6 +1254,9 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                     // a less loaded chip does not shorten, while the issue-bound general items do run faster: those start
                     // later (2048 queries of the cfg5 law -11 %, 4096 -5 %, 512 -4 %; ab16_order_key_small_batches.txt).
                     if (fine_cut && hg.cls == 0) key = key * 5 / 8;
+                    // K > 32: the streaming items pay more per posting than the work units (fitted at K = 10) say — fewer waves
+                    // per CU, larger candidate buffers — so the general items start later there too (cfg3 -2.6 %, at K = 64 -2.3 %)
+                    else if (auto_mode && k > 32 && hg.cls == 0) key = key * 3 / 4;
                     const bool wide = auto_mode && hg.g.term_count > 16;
                     const uint32_t bucket = order_bucket(key);
                     for (uint32_t i = 0; i < ns; i++) {

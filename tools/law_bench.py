@@ -74,6 +74,7 @@ def laws():
     L["cfg5_q2048"] = (workloads.cfg5_queries(2048, 2005), 10)
     L["cfg5_q512"] = (workloads.cfg5_queries(512, 2005), 10)
     L["cfg3_k64"] = (workloads.cfg3_queries(), 64)
+    L["cfg3_seed9"] = (workloads.cfg3_queries(4096, 9), 100)
     L["hot5_k10"] = ([" ".join(T(r) for r in (1, 2, 3, 4, 5))] * 1024, 10)
     return L
 
