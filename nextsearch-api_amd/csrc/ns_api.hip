@@ -240,7 +240,7 @@ static constexpr uint32_t kSplitWorkSmallK = 98304, kSplitWorkLargeK = 131072;
 static constexpr uint64_t kWorkForeign = 8, kWorkTile = 2;
 static constexpr uint32_t kSkipMinCount = 64;   // shorter lists are never looked up in the skip registry (ns_segment_build_skips)
 // per-item, per-term constants of the launch-order key (fitted to per-item timestamps, tools/dbg/item_times.py)
-static constexpr uint64_t kItemTermGeneral = 10000, kItemTermThin = 3000, kItemTermTile = 8000;
+static constexpr uint64_t kItemTermGeneral = 4000, kItemTermThin = 3000, kItemTermTile = 8000;   // general re-fitted in round 2 (10000 -> 4000: ab16)
 
 template <int HK, int FB>
 static void launch_dscore(bool and_mode, uint32_t n_items, hipStream_t st, const DevWItem* items, const DevTerm* terms,
