@@ -159,6 +159,9 @@ struct ns_ctx {
     // Batches alternate between the ctx's stream and this second one when overlap is on (ns_ctx_set_overlap): the
     // head of batch i+1 then fills the wave slots that the draining tail of batch i leaves idle.
     hipStream_t alt_stream = nullptr;
+    // Large descriptor uploads are pulled by a kernel on a stream of their own (highest priority), so that batch i+1's upload
+    // runs NEXT TO batch i's scoring kernel instead of behind it on the batch's stream or in the shared DMA queue.
+    hipStream_t pull_stream = nullptr;
     bool overlap = false, flip = false;
     std::string err;
     std::string devname;
@@ -299,6 +302,11 @@ extern "C" int ns_ctx_create(int device, ns_ctx** out) {
     }
     ctx->stream = ctx->own_stream;
     if (hipStreamCreateWithFlags(&ctx->alt_stream, hipStreamNonBlocking) != hipSuccess) { ctx->alt_stream = nullptr; (void)hipGetLastError(); }
+    {
+        int lo_pri = 0, hi_pri = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri);
+        if (hipStreamCreateWithPriority(&ctx->pull_stream, hipStreamNonBlocking, hi_pri) != hipSuccess) { ctx->pull_stream = nullptr; (void)hipGetLastError(); }
+    }
     *out = ctx;
     return NS_OK;
 }
@@ -308,6 +316,7 @@ extern "C" void ns_ctx_destroy(ns_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->alt_stream) (void)hipStreamSynchronize(ctx->alt_stream);
+    if (ctx->pull_stream) (void)hipStreamSynchronize(ctx->pull_stream);
     for (ns_seg* s : ctx->segs) {
         if (!s) continue;
         seg_free_device_fwd(s);
@@ -320,6 +329,7 @@ extern "C" void ns_ctx_destroy(ns_ctx* ctx) {
     if (ctx->up_done) (void)hipEventDestroy(ctx->up_done);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->alt_stream) (void)hipStreamDestroy(ctx->alt_stream);
+    if (ctx->pull_stream) (void)hipStreamDestroy(ctx->pull_stream);
     prep_free(ctx->prep);
     delete ctx;
 }
@@ -544,6 +554,7 @@ extern "C" int ns_segment_release(ns_ctx* ctx, ns_seg* seg) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->alt_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->alt_stream));
+    if (ctx->pull_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->pull_stream));
     seg_free_staging(seg);
     seg_free_device(seg);
     if (!seg->pending) ctx->segs[seg->id] = nullptr;
@@ -1072,7 +1083,10 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
     unsigned width = 1;
     if (n_queries >= 3000 && ctx->prep_threads != 1) {
         unsigned want = ctx->prep_threads ? ctx->prep_threads : std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 8u);
-        width = std::max(1u, std::min<unsigned>(want, n_queries / 1500));
+        // one thread per ~1500 queries or ~6000 term refs, whichever asks for more (a query over 8 segments carries 8x the refs)
+        uint64_t n_refs = 0;
+        for (uint32_t q = 0; q < n_queries; q++) n_refs += queries[q].term_count;
+        width = std::max(1u, std::min<unsigned>(want, std::max<unsigned>(n_queries / 1500, (unsigned)std::min<uint64_t>(n_refs / 6000, 64))));
     }
     if (width > 1 && (!P.pool || P.pool->width() < width)) { delete P.pool; P.pool = new ForkJoin(width); }
     if (P.slices.size() < width) P.slices.resize(width);
@@ -1477,12 +1491,22 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
             // streams go through one in-order DMA queue, where batch i+1's upload would sit behind batch i's result copy
             // — i.e. wait for batch i's kernels — and batch i+1's kernels with it (measured: 0.12 ms between consecutive
             // batches on two streams, as much as on one)
-            if (up_bytes <= kPullUploadBytes || ctx->overlap)
-                hipLaunchKernelGGL(k_pull, dim3((uint32_t)((up_bytes / 16 + 255) / 256)), dim3(256), 0, b->st,
+            // A LARGE upload (a 16384-query batch: 2.7 MB; 4096 queries over 8 segments: 6.5 MB = 0.2-0.25 ms) is pulled on the
+            // ctx's pull stream and the batch's stream waits for it: it then runs next to the previous batch's scoring kernel
+            // on one stream as on two.
+            if (up_bytes > kPullUploadBytes && ctx->pull_stream) {
+                hipLaunchKernelGGL(k_pull, dim3((uint32_t)((up_bytes / 16 + 255) / 256)), dim3(256), 0, ctx->pull_stream,
                                    (uint4*)base, (const uint4*)hb, (uint32_t)(up_bytes / 16));
-            else
-                chk(hipMemcpyAsync(base, hb, up_bytes, hipMemcpyHostToDevice, b->st));
-            chk(hipEventRecord(ctx->up_done, b->st));
+                chk(hipEventRecord(ctx->up_done, ctx->pull_stream));
+                chk(hipStreamWaitEvent(b->st, ctx->up_done, 0));
+            } else {
+                if (up_bytes <= kPullUploadBytes || ctx->overlap)
+                    hipLaunchKernelGGL(k_pull, dim3((uint32_t)((up_bytes / 16 + 255) / 256)), dim3(256), 0, b->st,
+                                       (uint4*)base, (const uint4*)hb, (uint32_t)(up_bytes / 16));
+                else
+                    chk(hipMemcpyAsync(base, hb, up_bytes, hipMemcpyHostToDevice, b->st));
+                chk(hipEventRecord(ctx->up_done, b->st));
+            }
             if (e == hipSuccess) ctx->up_busy = true;
         } else {
             chk(hipMemcpyAsync(base, hb, up_bytes, hipMemcpyHostToDevice, b->st));
