@@ -429,13 +429,11 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
                     if (wballot(scan) != 0ull) {
                         if (scan) {
                             const uint4 q = ent4[b];
-                            uint32_t m = 0;   // the entry of the same docId, if any
-                            m = ((q.x ^ mine) < 256u) ? q.x : m;
-                            m = ((q.y ^ mine) < 256u) ? q.y : m;
-                            m = ((q.z ^ mine) < 256u) ? q.z : m;
-                            m = ((q.w ^ mine) < 256u) ? q.w : m;
+                            // entry ^ mine is below 256 exactly for the entry of the same docId (at most one), and then it is
+                            // owner ^ me; an empty entry (0) gives `mine`, whose top bit is set: one minimum finds the match
+                            const uint32_t tmin = min(min(q.x ^ mine, q.y ^ mine), min(q.z ^ mine, q.w ^ mine));
                             pos = (q.x >> 31) + (q.y >> 31) + (q.z >> 31) + (q.w >> 31);   // entries fill a bucket in order
-                            if (m != 0) { own = m & 255u; pending = false; }
+                            if (tmin < 256u) { own = tmin ^ me; pending = false; }
                             scan = false;
                         }
                     }
