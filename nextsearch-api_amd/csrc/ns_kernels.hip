@@ -412,6 +412,17 @@ __global__ void __launch_bounds__(NT) k_score(const DevItem* __restrict__ items,
 // leave.  Cost is independent of K and linear in rows / 256.
 __host__ __device__ inline bool merge_is_wide(uint32_t part_count, uint32_t K) { return part_count > 64 && part_count >= K; }
 
+constexpr int kMergeStage = 2048;   // entries k_merge stages in LDS per query
+__device__ __forceinline__ uint32_t merge_wave_max(uint32_t v) {   // DPP reduction (row_shr / row_bcast forms), wave-uniform result
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 __device__ __forceinline__ void merge_rows_wave(uint32_t q, uint32_t pb, uint32_t pc, const Hit* __restrict__ part_hits,
                                                 const uint32_t* __restrict__ part_nhits, Hit* __restrict__ out_hits,
                                                 uint32_t* __restrict__ out_nhits, uint64_t* __restrict__ out_found, uint64_t found,
@@ -525,6 +536,58 @@ __global__ void __launch_bounds__(256) k_merge(const DevQuery* __restrict__ quer
                 h.doc = 0xFFFFFFFFu;
             }
             out_hits[(uint64_t)q * K + lane] = h;
+        }
+        if (lane == 0) {
+            out_nhits[q] = produced;
+            out_found[q] = found;
+        }
+        return;
+    }
+    if (pc <= 64u && pc * K <= (uint32_t)kMergeStage) {
+        // Up to 2048 entries in at most 64 rows (cfg3: 4-16 rows of K = 100): the scores' order bits are staged in LDS and
+        // the K rounds run out of it — lane r keeps row r's position and head in registers, one DPP maximum picks the round's
+        // score, the lowest lane that holds it wins (rows of a query ascend in (segment, doc range), and inside a row equal
+        // scores ascend in docId: the canonical tie order), the winner re-reads its head from LDS.  The tournament below pays
+        // two dependent GLOBAL round trips per round (row heads kept in memory): 100 rounds = 0.1 ms for a K = 100 batch.
+        __shared__ uint32_t s_sc[4][kMergeStage];
+        __shared__ uint16_t s_win[4][128];
+        uint32_t* sc = s_sc[threadIdx.x >> 6];
+        uint16_t* win = s_win[threadIdx.x >> 6];
+        for (uint32_t e = lane; e < pc * K; e += 64) {
+            const uint32_t r = e / K, i = e - r * K;
+            sc[e] = (i < part_nhits[pb + r]) ? order_bits(part_hits[(uint64_t)(pb + r) * K + i].score) : 0u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t h = 0;
+        uint32_t cur = ((uint32_t)lane < pc) ? sc[(uint32_t)lane * K] : 0u;   // 0 == nothing (left)
+        uint32_t produced = 0;
+        for (; produced < K; produced++) {
+            const uint32_t ms = merge_wave_max(cur);
+            if (ms == 0u) break;
+            const uint32_t w = (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(cur == ms));
+            if ((uint32_t)lane == w) {
+                win[produced] = (uint16_t)((w << 7) | h);
+                h++;
+                cur = (h < K) ? sc[w * K + h] : 0u;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        Hit* oh = out_hits + (uint64_t)q * K;
+        for (uint32_t i = lane; i < K; i += 64) {
+            Hit hh;
+            if (i < produced) {
+                const uint32_t code = win[i];
+                hh = part_hits[(uint64_t)(pb + (code >> 7)) * K + (code & 127u)];
+            } else {
+                hh.score = -__builtin_inff();
+                hh.seg = 0xFFFFFFFFu;
+                hh.doc = 0xFFFFFFFFu;
+            }
+            oh[i] = hh;
         }
         if (lane == 0) {
             out_nhits[q] = produced;
