@@ -1245,9 +1245,9 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                         uint32_t p2 = 1;
                         while (p2 < ns) p2 <<= 1;
                         if (!small_mode && (uint64_t)ns * ns * 2 < (uint64_t)p2 * p2) p2 >>= 1;   // a batch that leaves wave slots idle never gets fewer items
-                        // K > 32: a general or doc-tile group that is cut at all is cut into at least 8 ranges (cfg3 -5.7 %, at
-                        // K = 64 -6 %, another seed -5.9 %; at K <= 32 the same rule costs 2 %: ab14 / ab19)
-                        if (k > 32 && hg.cls != 1 && p2 < 8) p2 = 8;
+                        // K > 32: a group that is cut at all is cut into at least 8 ranges (cfg3 -7 %, at K = 64 -7 %, another seed
+                        // -7 %; 16 is too many; at K <= 32 the same rule costs 2 %: ab14 / ab19)
+                        if (k > 32 && p2 < 8) p2 = 8;
                         ns = std::min<uint32_t>(p2, std::min<uint32_t>(sg.n_docs, 4096));
                     }
                     // Skip tables (ns_segment_build_skips): a doc-tile group walks the grid of its lists' tables; a group of the
