@@ -162,10 +162,6 @@ struct ns_ctx {
     // Large descriptor uploads are pulled by a kernel on a stream of their own (highest priority), so that batch i+1's upload
     // runs NEXT TO batch i's scoring kernel instead of behind it on the batch's stream or in the shared DMA queue.
     hipStream_t pull_stream = nullptr;
-    // NS_RUN_FETCH: the results' D2H copy runs on a stream of its own behind the batch's last kernel, so that the next batch's
-    // kernels on the batch's stream do not wait for it (4.9 MB at K = 100: 0.1 ms per batch)
-    hipStream_t down_stream = nullptr;
-    hipEvent_t down_gate = nullptr;
     bool overlap = false, flip = false;
     std::string err;
     std::string devname;
@@ -310,8 +306,6 @@ extern "C" int ns_ctx_create(int device, ns_ctx** out) {
         int lo_pri = 0, hi_pri = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri);
         if (hipStreamCreateWithPriority(&ctx->pull_stream, hipStreamNonBlocking, hi_pri) != hipSuccess) { ctx->pull_stream = nullptr; (void)hipGetLastError(); }
-        if (hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking) != hipSuccess) { ctx->down_stream = nullptr; (void)hipGetLastError(); }
-        if (ctx->down_stream && hipEventCreateWithFlags(&ctx->down_gate, hipEventDisableTiming) != hipSuccess) { ctx->down_gate = nullptr; (void)hipGetLastError(); }
     }
     *out = ctx;
     return NS_OK;
@@ -323,7 +317,6 @@ extern "C" void ns_ctx_destroy(ns_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->alt_stream) (void)hipStreamSynchronize(ctx->alt_stream);
     if (ctx->pull_stream) (void)hipStreamSynchronize(ctx->pull_stream);
-    if (ctx->down_stream) (void)hipStreamSynchronize(ctx->down_stream);
     for (ns_seg* s : ctx->segs) {
         if (!s) continue;
         seg_free_device_fwd(s);
@@ -337,8 +330,6 @@ extern "C" void ns_ctx_destroy(ns_ctx* ctx) {
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->alt_stream) (void)hipStreamDestroy(ctx->alt_stream);
     if (ctx->pull_stream) (void)hipStreamDestroy(ctx->pull_stream);
-    if (ctx->down_stream) (void)hipStreamDestroy(ctx->down_stream);
-    if (ctx->down_gate) (void)hipEventDestroy(ctx->down_gate);
     prep_free(ctx->prep);
     delete ctx;
 }
@@ -564,7 +555,6 @@ extern "C" int ns_segment_release(ns_ctx* ctx, ns_seg* seg) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->alt_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->alt_stream));
     if (ctx->pull_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->pull_stream));
-    if (ctx->down_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->down_stream));
     seg_free_staging(seg);
     seg_free_device(seg);
     if (!seg->pending) ctx->segs[seg->id] = nullptr;
@@ -1636,7 +1626,6 @@ extern "C" int ns_batch_run(ns_batch* b, int run_flags) {
     HIPCHK(ctx, hipGetLastError());
     b->ran = true;
     b->done_recorded = false;
-    hipStream_t done_on = st;   // where this run's last operation is enqueued
     if (run_flags & NS_RUN_FETCH) {
         const bool own_outputs = b->o_hits == b->d_hits && b->o_nhits == b->d_nhits && b->o_found == b->d_found;
         if (!own_outputs) return fail(ctx, NS_E_STATE, "NS_RUN_FETCH: the batch writes into caller-bound device buffers (ns_batch_bind_outputs); there is nothing to fetch");
@@ -1668,19 +1657,12 @@ extern "C" int ns_batch_run(ns_batch* b, int run_flags) {
                 ctx->down_slots[(size_t)slot].busy = true;
                 b->down_slot = slot;
             }
-            if (ctx->down_stream && ctx->down_gate) {   // behind this batch's kernels, next to the next batch's
-                HIPCHK(ctx, hipEventRecord(ctx->down_gate, st));
-                HIPCHK(ctx, hipStreamWaitEvent(ctx->down_stream, ctx->down_gate, 0));
-                HIPCHK(ctx, hipMemcpyAsync(ctx->down_slots[(size_t)b->down_slot].p, b->d_hits, b->out_span, hipMemcpyDeviceToHost, ctx->down_stream));
-                done_on = ctx->down_stream;
-            } else {
-                HIPCHK(ctx, hipMemcpyAsync(ctx->down_slots[(size_t)b->down_slot].p, b->d_hits, b->out_span, hipMemcpyDeviceToHost, st));
-            }
+            HIPCHK(ctx, hipMemcpyAsync(ctx->down_slots[(size_t)b->down_slot].p, b->d_hits, b->out_span, hipMemcpyDeviceToHost, st));
         }
     }
     // completion event of THIS run: destroy (and a NS_RUN_FETCH fetch) wait for it instead of for the whole stream
     if (!b->done) HIPCHK(ctx, hipEventCreateWithFlags(&b->done, hipEventDisableTiming));
-    HIPCHK(ctx, hipEventRecord(b->done, done_on));
+    HIPCHK(ctx, hipEventRecord(b->done, st));
     b->done_recorded = true;
     b->fetch_enqueued = (run_flags & NS_RUN_FETCH) != 0;
     return NS_OK;
