@@ -87,6 +87,20 @@ def host_info():
     return {"nproc": os.cpu_count(), "cpu_model": model}
 
 
+def lib_info():
+    """Which native libraries this process measured: path and sha256 (first 16 hex digits) of the two in-tree .so files."""
+    import hashlib
+    out = {}
+    for name in ("libnextsearch_hip.so", "libnextsearch_host.so"):
+        p = os.path.join(PKG, name)
+        try:
+            with open(p, "rb") as f:
+                out[name] = hashlib.sha256(f.read()).hexdigest()[:16]
+        except OSError:
+            out[name] = None
+    return out
+
+
 def cpu_baselines(index_dir, queries, k, budget_s):
     """The CPU side of SURVEY 8(d), on THIS box's host cores, each on a bounded sample of the same workload:
       reference -O2, 1 core   cord19::Engine::search compiled from the reference's sources (oracle/_ref/ref_driver); one
@@ -216,8 +230,31 @@ def main():
     total_ms = kinfo.sum_total_ms / max(kinfo.timed_runs, 1)
 
     # ---- value leg: K pipelined steps at the C-ABI boundary ----
+    # A serving loop sees a different batch every step: the steps rotate over ROT distinct batches of the same query law and
+    # size (batch 0 = the kernel leg's; batch i = seed + 104729 i), so the device never sees the same launch twice in a row
+    # (other items, other launch order, other L2 / Infinity-Cache footprint).  Every batch's expected answer is computed once,
+    # untimed, one batch at a time; the timed region's last step is compared with its batch's.
+    ROT = 4
     elapsed = None
     if not args.kernel_only:
+        if strong:
+            rot_queries = [all_queries] + [gen(Q, seed + 104729 * i) for i in range(1, ROT)]
+            rot_local = [qs_[lo:hi] for qs_ in rot_queries]
+        else:
+            rot_queries = None
+            rot_local = [queries] + [gen(Q, seed + 7919 * rank + 104729 * i) for i in range(1, ROT)]
+        rot = []          # per batch: (qd, refs) of THIS rank's shard
+        rot_expect = []   # per batch: (hits, nhits, found) of this rank's shard, from an unpipelined run
+        for i, qs_ in enumerate(rot_local):
+            if i == 0:
+                rot.append((qd, refs)); rot_expect.append((k_hits, k_nhits, k_found))
+                continue
+            qd_i, refs_i, us_i = eng.build_refs(qs_)
+            assert us_i.all() and len(qd_i) == Qr
+            rb = nsbind.prepare_raw(eng.ctx, qd_i, refs_i, K, flags)
+            rb.run(timed=False); rb.sync()
+            rot.append((qd_i, refs_i)); rot_expect.append(rb.fetch())
+            rb.close()
         L.ns_ctx_set_overlap(eng.ctx, 0 if args.no_overlap else 1)
         depth = max(1, args.depth)
         if dist is None:
@@ -225,7 +262,7 @@ def main():
 
             def run_steps(n):
                 last = None
-                for res in nsbind.pipelined_search(eng.ctx, [(qd, refs)] * n, K, flags, out=out, depth=depth):
+                for res in nsbind.pipelined_search(eng.ctx, [rot[i % ROT] for i in range(n)], K, flags, out=out, depth=depth):
                     last = res
                 return last
 
@@ -235,9 +272,10 @@ def main():
             last = run_steps(args.steps)
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
-            # the timed region's results are real: the last step's host buffers equal the kernel leg's
-            assert last[0].tobytes() == k_hits.tobytes() and last[1].tobytes() == k_nhits.tobytes() and last[2].tobytes() == k_found.tobytes(), \
-                "pipelined results differ from the kernel leg's"
+            # the timed region's results are real: the last step's host buffers equal what its batch gives one batch at a time
+            e_hits, e_nhits, e_found = rot_expect[(args.steps - 1) % ROT]
+            assert last[0].tobytes() == e_hits.tobytes() and last[1].tobytes() == e_nhits.tobytes() and last[2].tobytes() == e_found.tobytes(), \
+                "pipelined results differ from the unpipelined run of the same batch"
         else:
             # every rank: prepare(own shard) -> kernels into ITS packed block -> ONE all-gather of the blocks; up to `depth`
             # steps in flight (the host only waits for the step that left the pipeline)
@@ -258,7 +296,7 @@ def main():
                         flight.popleft()()
                     st = streams[i % len(streams)]
                     L.ns_ctx_set_stream(eng.ctx, st.cuda_stream)
-                    b = nsbind.prepare_raw(eng.ctx, qd, refs, K, flags)
+                    b = nsbind.prepare_raw(eng.ctx, *rot[i % ROT], K, flags)
                     blk = blocks[i % depth]
                     b.bind_outputs(blk.data_ptr(), blk.data_ptr() + off_n, blk.data_ptr() + off_f)
                     b.run(timed=False)
@@ -286,10 +324,28 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-            # sanity: the gathered blocks hold this rank's own kernel-leg results at its place
+            # The gathered block of the LAST timed step, checked on every rank: this rank's own rows — hits, nhits, found — equal
+            # what its shard of that batch gives one batch at a time; and under strong scaling (every rank knows the whole
+            # global batch) ALL ranks' rows equal this rank's own unsharded answer to the global batch, computed here once.
             gh, gn, gf = shard.packed_views(gathered[(args.steps - 1) % depth], per, K, n_gpus)
-            assert np.array_equal(gn[rank, :Qr].cpu().numpy().astype(np.uint32), k_nhits) and np.array_equal(gf[rank, :Qr].cpu().numpy().astype(np.uint64), k_found), \
-                "gathered results differ from the kernel leg's"
+            li = (args.steps - 1) % ROT
+            e_hits, e_nhits, e_found = rot_expect[li]
+            g_hits = gh.cpu().numpy().view(nsbind.HIT_DTYPE).reshape(n_gpus, per, K)
+            g_nhits = gn.cpu().numpy().astype(np.uint32)
+            g_found = gf.cpu().numpy().astype(np.uint64)
+            assert g_hits[rank, :Qr].tobytes() == e_hits.tobytes() and np.array_equal(g_nhits[rank, :Qr], e_nhits) and np.array_equal(g_found[rank, :Qr], e_found), \
+                "gathered results (own rows) differ from the unpipelined run of the same batch"
+            if strong:
+                gq, grefs, gus = eng.build_refs(rot_queries[li])
+                assert gus.all()
+                gb = nsbind.prepare_raw(eng.ctx, gq, grefs, K, flags)
+                gb.run(timed=False); gb.sync()
+                w_hits, w_nhits, w_found = gb.fetch()
+                gb.close()
+                for r in range(n_gpus):
+                    a, b_ = shard.shard_bounds(Q, r, n_gpus)
+                    assert g_hits[r, :b_ - a].tobytes() == w_hits[a:b_].tobytes() and np.array_equal(g_nhits[r, :b_ - a], w_nhits[a:b_]) \
+                        and np.array_equal(g_found[r, :b_ - a], w_found[a:b_]), f"gathered rows of rank {r} differ from the unsharded answer"
         L.ns_ctx_set_overlap(eng.ctx, 0)
 
     # ---- extra legs (N = 1 only; reported next to the headline, never as `value`) ----
@@ -394,6 +450,7 @@ def main():
                 "k": K,
                 "parallelism": (f"query-sharded x{n_gpus}: index replicated, " + ("one global batch in contiguous shards" if strong else "a full batch per rank")
                                 + (", ONE RCCL all-gather of the packed result blocks per step" if n_gpus > 1 else "")),
+                "batches": "the steps rotate over 4 distinct batches of the law (batch 0 = the roofline leg's; seeds + 104729 i)",
                 "timed_region": ("per step: ns_batch_prepare from host-resident term refs (regroup, work items, H2D) -> scoring + merge kernels -> "
                                  + ("results in host memory" if n_gpus == 1 else "all-gather of all ranks' results on the device")
                                  + f"; {args.depth} steps in flight per ctx" + ("" if args.no_overlap else ", alternating between two streams")) if elapsed else "kernel leg only (--kernel-only)",
@@ -421,6 +478,7 @@ def main():
             "kernel_only": {"value": Qr * n_gpus * args.steps / kernel_elapsed, "unit": "queries/s", "ms_per_step": kernel_elapsed / args.steps * 1e3,
                             "what": "device-only: the prepared batch re-run with descriptors resident in HBM (round 1's `value`)"},
             "host": host_info(),
+            "library": lib_info(),
         }
         if n_gpus == 1 and args.cpu_seconds > 0 and flags == 0 and not args.kernel_only:
             cb, allcb = cpu_baselines(index_dir, queries, K, args.cpu_seconds)

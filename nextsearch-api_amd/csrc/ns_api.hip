@@ -19,6 +19,7 @@
 
 #include "../../include/nextsearch_hip.h"
 #include "ns_internal.h"
+#include "ns_forkjoin.hpp"
 #include "ns_kernels.hip"
 #include "ns_wave_kernel.hip"
 #include "ns_driver_kernel.hip"
@@ -31,57 +32,6 @@ using namespace ns;
 static_assert(sizeof(ns_hit) == sizeof(Hit), "ns_hit layout");
 
 
-// Fork-join over a fixed set of host threads (ns_batch_prepare's phases).  run(n, fn) calls fn(0..n-1), task i on
-// worker i (the calling thread takes task 0), and returns when all are done.  Workers sleep between batches.
-class ForkJoin {
-public:
-    explicit ForkJoin(unsigned width) : width_(std::max(1u, width)) {
-        for (unsigned i = 1; i < width_; i++) workers_.emplace_back([this, i]() { loop(i); });
-    }
-    ~ForkJoin() {
-        { std::lock_guard<std::mutex> l(m_); stop_ = true; gen_++; }
-        wake_.notify_all();
-        for (auto& t : workers_) t.join();
-    }
-    unsigned width() const { return width_; }
-    void run(unsigned n, const std::function<void(unsigned)>& fn) {
-        n = std::min(n, width_);
-        if (n <= 1) { if (n) fn(0); return; }
-        { std::lock_guard<std::mutex> l(m_); fn_ = &fn; n_ = n; pending_ = n - 1; gen_++; }
-        wake_.notify_all();
-        fn(0);
-        std::unique_lock<std::mutex> l(m_);
-        done_.wait(l, [this]() { return pending_ == 0; });
-        fn_ = nullptr;
-    }
-private:
-    void loop(unsigned me) {
-        uint64_t seen = 0;
-        for (;;) {
-            const std::function<void(unsigned)>* fn = nullptr;
-            {
-                std::unique_lock<std::mutex> l(m_);
-                wake_.wait(l, [&]() { return gen_ != seen; });
-                seen = gen_;
-                if (stop_) return;
-                if (me < n_) fn = fn_;
-            }
-            if (fn) {
-                (*fn)(me);
-                std::lock_guard<std::mutex> l(m_);
-                if (--pending_ == 0) done_.notify_one();
-            }
-        }
-    }
-    unsigned width_;
-    std::vector<std::thread> workers_;
-    std::mutex m_;
-    std::condition_variable wake_, done_;
-    const std::function<void(unsigned)>* fn_ = nullptr;
-    unsigned n_ = 0, pending_ = 0;
-    uint64_t gen_ = 0;
-    bool stop_ = false;
-};
 struct ns_prep;
 static void prep_free(ns_prep* p);
 
@@ -167,6 +117,7 @@ struct ns_ctx {
     std::string devname;
     int n_cus = 0;
     std::vector<ns_seg*> segs;   // indexed by seg_id
+    std::vector<ns_seg*> pending_uploads;   // begun (ns_segment_upload_begin), not yet ended or released: freed with the ctx
     uint32_t variant = 0;
     uint32_t min_items = 0;
     uint32_t split_postings = 0;
@@ -189,10 +140,15 @@ struct ns_ctx {
     bool use_skips = true;     // doc-tile groups walk the skip grid when their lists have skip tables (ns_ctx_use_skips)
     ns_prep* prep = nullptr;   // ns_batch_prepare's host threads and per-thread scratch, kept from batch to batch
     unsigned prep_threads = 0; // 0 = automatic (up to 8); 1 = prepare on the calling thread only (ns_ctx_set_host_threads)
+    // Launch order inside coarse run-time classes (see "XCD dealing" in ns_batch_prepare): 1 = on.  The environment variables
+    // NS_ORDER_MODE (0 = off) / NS_ORDER_COARSE (log2 of the fine buckets per class) override it for experiments; read at
+    // ns_ctx_create.
+    int order_mode = 1, order_coarse = 3;
 };
 
 static thread_local std::string g_create_err;
 static void seg_free_device_fwd(ns_seg* s);
+static void seg_free_staging_fwd(ns_seg* s);
 
 static int fail(ns_ctx* ctx, int code, const char* fmt, ...) {
     char buf[512];
@@ -301,6 +257,8 @@ extern "C" int ns_ctx_create(int device, ns_ctx** out) {
         return rc;
     }
     ctx->stream = ctx->own_stream;
+    if (const char* om = std::getenv("NS_ORDER_MODE")) ctx->order_mode = std::atoi(om);
+    if (const char* oc = std::getenv("NS_ORDER_COARSE")) ctx->order_coarse = std::max(0, std::min(11, std::atoi(oc)));
     if (hipStreamCreateWithFlags(&ctx->alt_stream, hipStreamNonBlocking) != hipSuccess) { ctx->alt_stream = nullptr; (void)hipGetLastError(); }
     {
         int lo_pri = 0, hi_pri = 0;
@@ -319,6 +277,11 @@ extern "C" void ns_ctx_destroy(ns_ctx* ctx) {
     if (ctx->pull_stream) (void)hipStreamSynchronize(ctx->pull_stream);
     for (ns_seg* s : ctx->segs) {
         if (!s) continue;
+        seg_free_device_fwd(s);
+        delete s;
+    }
+    for (ns_seg* s : ctx->pending_uploads) {   // uploads begun and never ended: their HBM, pinned staging and events go with the ctx
+        seg_free_staging_fwd(s);
         seg_free_device_fwd(s);
         delete s;
     }
@@ -369,6 +332,7 @@ static void seg_free_staging(ns_seg* s) {
 }
 static void seg_free_device(ns_seg* s);
 static void seg_free_device_fwd(ns_seg* s) { seg_free_device(s); }
+static void seg_free_staging_fwd(ns_seg* s) { seg_free_staging(s); }
 static void seg_free_device(ns_seg* s) {
     (void)hipFree(s->d_postings);
     (void)hipFree(s->d_norm);
@@ -497,6 +461,7 @@ extern "C" int ns_segment_upload_begin(ns_ctx* ctx, uint32_t seg_id, uint32_t n_
         s->norm_safe = n_docs > 0 && std::isfinite(avgdl) && avgdl > 0.0f && norm_of(dl_min) >= lo_ok && norm_of(dl_min) <= hi_ok &&
                        norm_of(dl_max) >= lo_ok && norm_of(dl_max) <= hi_ok;
     }
+    ctx->pending_uploads.push_back(s);
     *out = s;
     return NS_OK;
 }
@@ -528,6 +493,7 @@ extern "C" int ns_segment_upload_end(ns_ctx* ctx, ns_seg* s) {
     if (e != hipSuccess) return fail(ctx, NS_E_HIP, "segment upload: %s", hipGetErrorString(e));
     seg_free_staging(s);
     s->pending = false;
+    ctx->pending_uploads.erase(std::remove(ctx->pending_uploads.begin(), ctx->pending_uploads.end(), s), ctx->pending_uploads.end());
     if (ctx->segs.size() <= s->id) ctx->segs.resize(s->id + 1, nullptr);
     ctx->segs[s->id] = s;
     return NS_OK;
@@ -558,6 +524,7 @@ extern "C" int ns_segment_release(ns_ctx* ctx, ns_seg* seg) {
     seg_free_staging(seg);
     seg_free_device(seg);
     if (!seg->pending) ctx->segs[seg->id] = nullptr;
+    else ctx->pending_uploads.erase(std::remove(ctx->pending_uploads.begin(), ctx->pending_uploads.end(), seg), ctx->pending_uploads.end());
     delete seg;
     return NS_OK;
 }
@@ -1000,6 +967,7 @@ struct PrepSlice {
     // phase B
     std::vector<DevWItem> witems;
     std::vector<uint16_t> wbucket;        // launch-order bucket of each wave item; bit 15: > 16 terms (the "wide" instantiation)
+    std::vector<uint16_t> wshare;         // 12-bit locality key of the item: (segment, eighth of the doc space) << 4 | hash of its largest list -> XCD dealing
     std::vector<DevItem> items;
     std::vector<uint64_t> item_cost;
     std::vector<DevGroup> bgroups;
@@ -1015,7 +983,7 @@ struct PrepSlice {
         dterms.clear(); groups.clear(); qgroup_begin.clear(); seg_ids.clear();
         bounds_total = postings_total = total_work = 0; all_imp = true; all_pk = true;
         err_code = NS_OK; err_query = 0xFFFFFFFFu; err_msg.clear();
-        witems.clear(); wbucket.clear(); items.clear(); item_cost.clear(); bgroups.clear();
+        witems.clear(); wbucket.clear(); wshare.clear(); items.clear(); item_cost.clear(); bgroups.clear();
         n_rows = 0; direct = true;
         hist.assign(2 * kOrderBuckets, 0u);
         start.assign(2 * kOrderBuckets, 0u);
@@ -1036,6 +1004,10 @@ struct PrepSlice {
 
 struct ns_prep {
     std::vector<PrepSlice> slices;
+    std::vector<uint16_t> share_at;       // per launch position: the item's locality key (XCD dealing)
+    std::vector<uint32_t> bucket_pos;     // launch position at which each fine bucket of the narrow half starts (+ the end)
+    std::vector<std::vector<DevWItem>> deal_tmp;   // per host thread
+    std::vector<std::vector<uint32_t>> deal_pos;
     ForkJoin* pool = nullptr;
     ~ns_prep() { delete pool; }
 };
@@ -1276,6 +1248,14 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                     else if (auto_mode && k > 32 && hg.cls == 0) key = key * 3 / 4;
                     const bool wide = auto_mode && hg.g.term_count > 16;
                     const uint32_t bucket = order_bucket(key);
+                    // what the group's items read most of: its largest list (the driver of a driver-stream item)
+                    uint64_t big_off = 0;
+                    {
+                        const DevTerm* dt = S.dterms.data() + (hg.g.term_begin - S.term_off);
+                        uint32_t cm = 0;
+                        for (uint32_t ti = 0; ti < hg.g.term_count; ti++)
+                            if (dt[ti].count >= cm) { cm = dt[ti].count; big_off = dt[ti].list_off; }
+                    }
                     for (uint32_t i = 0; i < ns; i++) {
                         DevWItem it{};
                         it.query = q;
@@ -1295,7 +1275,12 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                         if (auto_mode) it.whole |= (hg.cls == 2 ? 2u : 0u) | (hg.cls == 1 ? 4u : 0u);
                         S.witems.push_back(it);
                         S.wbucket.push_back((uint16_t)(bucket | (wide ? 0x8000u : 0u)));
-                        S.hist[(wide ? kOrderBuckets : 0) + bucket]++;
+                        {
+                            uint64_t h = big_off * 0x9E3779B97F4A7C15ull;
+                            h ^= h >> 29;
+                            const uint32_t rr = (it.seg * 8u + (uint32_t)((uint64_t)it.doc_lo * 8u / std::max<uint32_t>(sg.n_docs, 1u))) & 255u;
+                            S.wshare.push_back((uint16_t)((rr << 4) | (uint32_t)(h & 15u)));
+                        }
                     }
                 } else {
                     DevGroup g = hg.g;
@@ -1335,13 +1320,16 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
     uint32_t n_class[3] = {0, 0, 0};
     {
         uint32_t pos = 0;
+        P.bucket_pos.assign(kOrderBuckets + 1, 0u);
         for (uint32_t half = 0; half < 2; half++) {
-            for (uint32_t bkt = 0; bkt < kOrderBuckets; bkt++)
+            for (uint32_t bkt = 0; bkt < kOrderBuckets; bkt++) {
+                if (half == 0) P.bucket_pos[bkt] = pos;
                 for (unsigned s = 0; s < width; s++) {
                     P.slices[s].start[half * kOrderBuckets + bkt] = pos;
                     pos += P.slices[s].hist[half * kOrderBuckets + bkt];
                 }
-            if (half == 0) n_class[0] = pos;
+            }
+            if (half == 0) { n_class[0] = pos; P.bucket_pos[kOrderBuckets] = pos; }
         }
         n_class[1] = pos - n_class[0];
         if (!auto_mode) { n_class[0] = n_class[1] = 0; }
@@ -1470,6 +1458,8 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
         std::vector<char> unstaged;
         if (!staged) unstaged.resize(up_bytes);
         char* hb = staged ? (char*)ctx->h_up : unstaged.data();
+        const bool deal = ctx->order_mode == 1 && auto_mode && n_class[0] >= 64;
+        if (deal && P.share_at.size() < n_witems) P.share_at.resize(n_witems);
         fork([&](unsigned si) {
             PrepSlice& S = P.slices[si];
             DevWItem* wdst = (DevWItem*)(hb + o_witems);
@@ -1477,13 +1467,61 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                 DevWItem it = S.witems[i];
                 it.out_slot = direct ? it.query : it.out_slot + S.row_off;
                 const uint32_t bk = S.wbucket[i];
-                wdst[S.start[((bk & 0x8000u) ? kOrderBuckets : 0) + (bk & 0x7FFFu)]++] = it;
+                const uint32_t at = S.start[((bk & 0x8000u) ? kOrderBuckets : 0) + (bk & 0x7FFFu)]++;
+                wdst[at] = it;
+                if (deal) P.share_at[at] = S.wshare[i];
             }
             if (!S.dterms.empty()) std::memcpy(hb + o_terms + (size_t)S.term_off * sizeof(DevTerm), S.dterms.data(), S.dterms.size() * sizeof(DevTerm));
             if (!S.bgroups.empty()) std::memcpy(hb + o_groups + (size_t)S.bgroup_off * sizeof(DevGroup), S.bgroups.data(), S.bgroups.size() * sizeof(DevGroup));
             for (uint32_t q = S.q0; q < S.q1; q++) dq[q].part_begin += S.row_off;
             if (S.q1 > S.q0) std::memcpy(hb + o_queries + (size_t)S.q0 * sizeof(DevQuery), dq.data() + S.q0, (size_t)(S.q1 - S.q0) * sizeof(DevQuery));
         });
+        // ---- XCD dealing.  The launch order is longest-estimated-run-time first (2048 fine buckets).  Inside a coarse class of
+        // 8 fine buckets (run times within ~19 % of each other) the order is free, and it is used for locality: workgroup i
+        // runs on XCD i % 8, each XCD has its own 4 MB L2, and items that read the same bytes — same segment, same part of
+        // the doc space, same largest list: the shards of a hot list that dozens of queries of a batch share — should meet
+        // in ONE L2 at about the same time, so that one of them pulls a line from HBM and the others hit it.  The items of a
+        // class are sorted by their 12-bit locality key (segment and eighth of the doc space first, then a hash of the
+        // largest list; counting sort, stable), the sorted sequence is cut into eight equal parts, and XCD x — the launch
+        // positions p with p % 8 == x — takes part x in order: one L2 per part of the doc space, neighbours in time share lists.
+        // Measured (profiles/r03): 20 x 1M-doc index, L2-miss traffic of the cfg5 launch 44.2 -> 30.9 GB, 7.24 -> 6.86 ms; the
+        // 1M-doc index 2.76 -> 2.67 ms.  O(items); the classes are spread over the prepare threads.
+        if (deal) {
+            DevWItem* wd = (DevWItem*)(hb + o_witems);
+            const uint32_t shift = (uint32_t)ctx->order_coarse;
+            const uint32_t n_cls = kOrderBuckets >> shift;
+            if (P.deal_tmp.size() < width) { P.deal_tmp.resize(width); P.deal_pos.resize(width); }
+            fork([&](unsigned si) {
+                std::vector<DevWItem>& tmp = P.deal_tmp[si];
+                std::vector<uint32_t>& ord = P.deal_pos[si];   // [0, n): sorted order (original indices); [n, n + 4097): bins
+                for (uint32_t c = si; c < n_cls; c += width) {
+                    const uint32_t p0 = P.bucket_pos[c << shift], p1 = P.bucket_pos[(c + 1) << shift];
+                    const uint32_t n = p1 - p0;
+                    if (n < 16) continue;
+                    const uint16_t* key = P.share_at.data() + p0;
+                    if (n <= 2048) {   // few items: sort (key, index) words; many: counting sort over the 4096 keys (both stable)
+                        ord.resize(n);
+                        for (uint32_t i = 0; i < n; i++) ord[i] = ((uint32_t)(key[i] & 4095u) << 16) | i;
+                        std::sort(ord.begin(), ord.end());
+                        for (uint32_t i = 0; i < n; i++) ord[i] &= 0xFFFFu;
+                    } else {
+                        ord.assign((size_t)n + 4097, 0u);
+                        uint32_t* bins = ord.data() + n;
+                        for (uint32_t i = 0; i < n; i++) bins[(key[i] & 4095u) + 1u]++;
+                        for (uint32_t k2 = 0; k2 < 4096; k2++) bins[k2 + 1] += bins[k2];
+                        for (uint32_t i = 0; i < n; i++) ord[bins[key[i] & 4095u]++] = i;
+                    }
+                    tmp.assign(wd + p0, wd + p1);
+                    uint32_t cur[8], end[8];
+                    for (uint32_t x = 0; x < 8; x++) { cur[x] = (uint32_t)((uint64_t)n * x / 8); end[x] = (uint32_t)((uint64_t)n * (x + 1) / 8); }
+                    for (uint32_t p = 0; p < n; p++) {
+                        uint32_t x = (p0 + p) & 7u;
+                        for (uint32_t tr = 0; tr < 8 && cur[x] >= end[x]; tr++) x = (x + 1) & 7u;   // a part one item short of its slots
+                        wd[p0 + p] = tmp[ord[cur[x]++]];
+                    }
+                }
+            });
+        }
         if (n_items) std::memcpy(hb + o_items, sorted_items.data(), (size_t)n_items * sizeof(DevItem));
         if (!segs.empty()) std::memcpy(hb + o_segs, segs.data(), segs.size() * sizeof(segs[0]));
         if (!wide_q.empty()) std::memcpy(hb + o_wideq, wide_q.data(), wide_q.size() * 4);
@@ -1538,6 +1576,14 @@ extern "C" int ns_batch_run(ns_batch* b, int run_flags) {
     if (!b) return NS_E_INVAL;
     ns_ctx* ctx = b->ctx;
     const int timed = run_flags & NS_RUN_TIMED;
+    // preconditions are checked BEFORE anything is enqueued, and the previous run's completion event stops counting from
+    // here on: whatever early return follows, ns_batch_destroy then falls back to synchronising the batch's stream instead
+    // of trusting an event that lies before kernels of this run
+    if (run_flags & NS_RUN_FETCH) {
+        const bool own_outputs = b->o_hits == b->d_hits && b->o_nhits == b->d_nhits && b->o_found == b->d_found;
+        if (!own_outputs) return fail(ctx, NS_E_STATE, "NS_RUN_FETCH: the batch writes into caller-bound device buffers (ns_batch_bind_outputs); there is nothing to fetch");
+    }
+    b->done_recorded = false;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = b->st;
     const bool and_mode = (b->flags & NS_FLAG_AND) != 0;
@@ -1625,10 +1671,7 @@ extern "C" int ns_batch_run(ns_batch* b, int run_flags) {
     if (timed) HIPCHK(ctx, hipEventRecord(ev[3], st));
     HIPCHK(ctx, hipGetLastError());
     b->ran = true;
-    b->done_recorded = false;
     if (run_flags & NS_RUN_FETCH) {
-        const bool own_outputs = b->o_hits == b->d_hits && b->o_nhits == b->d_nhits && b->o_found == b->d_found;
-        if (!own_outputs) return fail(ctx, NS_E_STATE, "NS_RUN_FETCH: the batch writes into caller-bound device buffers (ns_batch_bind_outputs); there is nothing to fetch");
         if (b->Q && ctx->down_owner != b) {   // (a small batch that owns h_down already has its results in host memory)
             if (b->down_slot < 0) {
                 int slot = -1;
@@ -1722,6 +1765,11 @@ extern "C" int ns_batch_fetch(ns_batch* b, ns_hit* hits_out, uint32_t* nhits_out
             if (nhits_out) std::memcpy(nhits_out, h + b->off_nhits, (size_t)b->Q * 4);
             if (found_out) std::memcpy(found_out, h + b->off_found, (size_t)b->Q * 8);
         }
+        // the pinned slot goes back to the ctx with the fetch (not only at destroy): a serving loop that fetches promptly may
+        // keep any number of batches alive.  A second fetch of this run takes the ordinary path (the device buffers still
+        // hold the results); the next NS_RUN_FETCH run acquires a slot again.
+        if (b->down_slot >= 0) { ctx->down_slots[(size_t)b->down_slot].busy = false; b->down_slot = -1; }
+        b->fetch_enqueued = false;
         return NS_OK;
     }
     if (b->Q && own_outputs && ctx->down_owner == b) {   // the results are already in host memory

@@ -126,8 +126,16 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
     constexpr uint32_t EMPTY = 0u;
     constexpr int LOG2NB = (NB == 64) ? 6 : (NB == 128 ? 7 : 8);
     constexpr uint32_t MAXSPAN = (1u << (LOG2NB + 15)) - 1u;   // docs per super-batch - 1
-#define NS_TAG(doc) (0x8000u | (((doc) >> LOG2NB) & 0x7FFFu))
-#define NS_IDENT(doc) ((NS_TAG(doc) << 16) | (((doc) & (uint32_t)(NB - 1)) << 8))
+    // Buckets are ORDER-PRESERVING within a super-batch [lo, hi]: bucket(doc) = ((doc - lo) * bm) >> 16 with
+    // bm = floor(NB * 2^16 / (hi - lo + 1)), i.e. the super-batch's doc span cut into NB equal ranges (a 24-bit multiply and
+    // a bit-field extract: the extract also keeps the index inside the table for docIds outside the span, which are never
+    // used).  The docs of one bucket differ by less than 2^15 (bm >= 2 because a super-batch spans at most NB * 2^15 docs),
+    // so the low 15 bits of doc - lo plus the home bucket pin the docId exactly.  What the order buys: the postings of ONE
+    // term arrive sorted by docId, so the lanes of a term that fall into the same bucket are NEIGHBOURS, and a lane's
+    // position inside its bucket is its distance from the first of them — ballot + prefix-max, no claim loop (below).
+#define NS_BUCKET(doc) ((uint32_t)__builtin_amdgcn_ubfe(__umul24((doc) - lo, bm), 16u, (uint32_t)LOG2NB))
+#define NS_TAG(doc) (0x8000u | (((doc) - lo) & 0x7FFFu))
+#define NS_IDENT(doc, bkt) ((NS_TAG(doc) << 16) | ((bkt) << 8))
     static_assert(NB == 64 || NB == 128 || NB == 256, "NB must be 64, 128 or 256");
     static_assert(FB % 64 == 0 && FB >= 64 && FB <= 256 && FB <= 2 * NB, "FB must be a multiple of 64, at most 256 and 2*NB");
     uint4* ent4 = reinterpret_cast<uint4*>(ent);
@@ -214,8 +222,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
     float theta = -__builtin_inff();
     uint32_t ncand = 0;
     uint32_t nsorted = 0;   // leading candidates already in descending order (left by the last shrink)
-    uint32_t found_lane = 0;   // per-lane part of `found` (foreign docs)
-    uint32_t found_s = 0;      // wave-uniform part (private driver postings)
+    uint32_t found_s = 0;      // `found`, wave-uniform: private driver postings and owners of table entries, counted by ballots
     bool ge_mode = false;   // a shrink happened inside the current super-batch: ties with theta may still win on docId
 
     // offer (score, doc) of the lanes where `cond` holds to the candidate buffer
@@ -289,6 +296,16 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
         const uint32_t span_hi = (last_doc - lo > MAXSPAN) ? (lo + MAXSPAN) : last_doc;
         const bool span_clamped = hi > span_hi && span_hi != last_doc;
         hi = min(hi, span_hi);
+        // the bucket function of this super-batch (see NS_BUCKET): bm = floor(NB * 2^16 / (hi - lo + 1)), exact
+        uint32_t bm;
+        {
+            const uint32_t spn1 = (hi >= lo ? hi - lo : 0u) + 1u;   // <= NB * 2^15 (span_hi)
+            bm = (uint32_t)((float)((uint32_t)NB << 16) * __builtin_amdgcn_rcpf((float)spn1));   // within a few units of the quotient
+            bm = (uint32_t)__builtin_amdgcn_readfirstlane((int)bm);
+            while ((uint64_t)bm * spn1 > (uint64_t)((uint32_t)NB << 16)) bm--;
+            while ((uint64_t)(bm + 1u) * spn1 <= (uint64_t)((uint32_t)NB << 16)) bm++;   // >= 2, since spn1 <= NB * 2^15
+            bm = min(bm, 0xFFFFFFu);   // 24-bit multiplier (spn1 == 1 with NB == 256; the only doc then has offset 0)
+        }
 
         // ================= 2. foreign postings -> table =================
         uint32_t ftj[FE];     // term of the lane's j-th foreign posting; after the claim: term | owner's posting number << 6 | entry index << 14
@@ -407,19 +424,70 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
 #pragma unroll
                 for (int j = 0; j < FE; j++) fx[j] = wqv[j] * fx[j];
             }
-            // ---- claim one entry per distinct docId WITHOUT LDS atomics (integer and float LDS atomics
-            //      are serialised per lane on gfx950): read the bucket; a matching entry names the doc's
-            //      owner; otherwise store our entry at the first free position and read it back — a wave's
-            //      LDS operations execute in order, so exactly one of the colliding entries survives;
-            //      equal docIds agree on the survivor (the OWNER of the doc's accumulator), everybody
-            //      else retries on the same bucket (or the next one when it is full). ----
+            // ---- the table of this super-batch: one entry per distinct foreign docId, WITHOUT LDS atomics (integer and
+            //      float LDS atomics are serialised per lane on gfx950) ----
+            // Pass A, the PRIMARY foreign term (the one with the largest window): its postings are sorted by docId and the
+            // bucket function is monotone, so the lanes of one bucket are consecutive lanes; the table is empty when the
+            // pass starts, so a lane's position in its bucket is (what the term's previous chunk left there) + (distance
+            // from the first lane of the bucket's run) — a ballot of run heads and a prefix maximum of their lane numbers
+            // (six DPP steps).  Every such lane stores its entry exactly once: no bucket read, no read-back, no retry.
+            // Lanes whose bucket is full (position >= 4) and every other term go through the claim loop of pass B.
+            uint32_t pterm = 0xFFFFFFFFu;
+            {
+                const uint32_t wmax = wave_max_dpp(w);
+                if (wmax >= 8u) pterm = (uint32_t)__builtin_ctzll(wballot(w == wmax));
+            }
+            if (pterm != 0xFFFFFFFFu) {
+                uint32_t carry_b = 0xFFFFFFFFu, carry_n = 0u;   // the bucket the term's previous chunk ended in, and its fill
+                bool sorted_ok = true;                           // wave-uniform
+#pragma unroll
+                for (int j = 0; j < FE; j++) {
+                    const bool isp = fok[j] && ftj[j] == pterm;
+                    const uint64_t pm = wballot(isp);
+                    if ((uint32_t)(j * 64) < total && pm != 0ull && sorted_ok) {   // uniform
+                        const uint32_t bkt = NS_BUCKET(fdoc[j]);
+                        const uint32_t bprev = (uint32_t)__builtin_amdgcn_ds_bpermute((lane - 1) << 2, (int)bkt);
+                        const bool prevp = __builtin_amdgcn_inverse_ballot_w64(pm << 1);
+                        // sorted docIds give non-decreasing buckets; a list that is not sorted keeps to the claim loop
+                        sorted_ok = wballot(isp && prevp && bkt < bprev) == 0ull &&
+                                    (carry_b == 0xFFFFFFFFu || rdlane(bkt, (uint32_t)__builtin_ctzll(pm)) >= carry_b);
+                        if (sorted_ok) {
+                            uint32_t hl = (isp && (!prevp || bkt != bprev)) ? (uint32_t)lane : 0u;   // run heads; prefix maximum = lane of the run's first lane
+                            hl = max(hl, dpp_mov<0x111, 0xf>(0u, hl));
+                            hl = max(hl, dpp_mov<0x112, 0xf>(0u, hl));
+                            hl = max(hl, dpp_mov<0x114, 0xf>(0u, hl));
+                            hl = max(hl, dpp_mov<0x118, 0xf>(0u, hl));
+                            hl = max(hl, dpp_mov<0x142, 0xa>(0u, hl));
+                            hl = max(hl, dpp_mov<0x143, 0xc>(0u, hl));
+                            const uint32_t pos = ((bkt == carry_b) ? carry_n : 0u) + ((uint32_t)lane - hl);
+                            const uint32_t at = bkt * 4u + pos;
+                            if (isp && pos < 4u) {
+                                ent[at] = NS_IDENT(fdoc[j], bkt) | (uint32_t)(j * 64 + lane);
+                                fmine[j] = true;
+                                ftj[j] |= ((uint32_t)(j * 64 + lane) << 6) | (at << 14);
+                            }
+                            const uint32_t last = 63u - (uint32_t)__builtin_clzll(pm);
+                            carry_b = rdlane(bkt, last);
+                            carry_n = rdlane(pos, last) + 1u;
+                            NS_CNT(15, (uint32_t)__popcll(wballot(isp && pos < 4u)));   // entries placed without a claim
+                        }
+                    }
+                }
+                wave_sync();
+            }
+            // Pass B, everybody else: read the bucket; a matching entry names the doc's owner; otherwise store our entry
+            // at the first free position and read it back — a wave's LDS operations execute in order, so exactly one
+            // of the colliding entries survives; equal docIds agree on the survivor (the OWNER of the doc's
+            // accumulator), everybody else retries on the same bucket (or the next one when it is full).
 #pragma unroll
             for (int j = 0; j < FE; j++) {
                 if ((uint32_t)(j * 64) >= total) continue;   // uniform
+                bool pending = fok[j] && !fmine[j];
+                if (wballot(pending) == 0ull) continue;      // uniform: the whole chunk was placed in pass A
                 const uint32_t me = (uint32_t)(j * 64 + lane);
-                const uint32_t mine = NS_IDENT(fdoc[j]) | me;
-                uint32_t b = fdoc[j] & (uint32_t)(NB - 1);
-                bool pending = fok[j];
+                uint32_t b = NS_BUCKET(fdoc[j]);
+                const uint32_t mine = NS_IDENT(fdoc[j], b) | me;
+                const bool todo = pending;
                 uint32_t slot = 0, own = 0;
                 bool scan = pending;   // lanes that have to read their (new) bucket
                 uint32_t pos = 0;
@@ -453,8 +521,10 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
                     }
                     wave_sync();
                 }
-                fmine[j] = fok[j] && own == me;
-                ftj[j] |= (own << 6) | (slot << 14);
+                if (todo) {
+                    fmine[j] = own == me;
+                    ftj[j] |= (own << 6) | (slot << 14);
+                }
             }
         }
 
@@ -608,7 +678,8 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
                 for (int j = 0; j < DE; j++) {
                     if (PK ? (dokm[j] == 0ull) : ((uint32_t)(j * 64) >= n)) continue;   // uniform: no posting of this round in the chunk
                     const uint32_t tag = NS_TAG(ps[j].x);
-                    uint32_t b = ps[j].x & (uint32_t)(NB - 1);
+                    const uint32_t hb = NS_BUCKET(ps[j].x);   // in range whatever the docId; only postings of this super-batch count (dokm)
+                    uint32_t b = hb;
                     uint4 q = ent4[b];
                     // first the 16-bit tags (one compare per entry); a tag match is verified below
                     const uint64_t cm = wballot((q.x >> 16) == tag) | wballot((q.y >> 16) == tag) |
@@ -616,7 +687,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
                     // full bucket without a tag match: the doc may sit in the next bucket (a 0.2% event per lane)
                     const uint64_t go = dokm[j] & (cm | wballot(q.w != EMPTY));
                     if (go != 0ull) {
-                        const uint32_t ident = NS_IDENT(ps[j].x);
+                        const uint32_t ident = NS_IDENT(ps[j].x, hb);
                         uint32_t m = 0;
                         bool more = __builtin_amdgcn_inverse_ballot_w64(go);
                         while (wballot(more) != 0ull) {
@@ -680,7 +751,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
                     ent[ftj[j] >> 14] = EMPTY;
                     if (AND) mcnt[j * 64 + lane] = 0;
                 }
-                found_lane += scored[j] ? 1u : 0u;
+                found_s += (uint32_t)__popcll(wballot(scored[j]));
                 NS_OFFER(scored[j], fin[j], fdoc[j]);
             }
             wave_sync();
@@ -698,6 +769,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
 #undef NS_PLAN_FOREIGN
 #undef NS_TAG
 #undef NS_IDENT
+#undef NS_BUCKET
 
 #ifdef NS_COUNT
     const unsigned long long cyc_t1_ = __builtin_readcyclecounter();
@@ -721,16 +793,9 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
         }
         oh[i] = h;
     }
-    uint32_t found = found_lane;
-    found += dpp_mov<0x111, 0xf>(0u, found);
-    found += dpp_mov<0x112, 0xf>(0u, found);
-    found += dpp_mov<0x114, 0xf>(0u, found);
-    found += dpp_mov<0x118, 0xf>(0u, found);
-    found += dpp_mov<0x142, 0xa>(0u, found);
-    found += dpp_mov<0x143, 0xc>(0u, found);
     if (lane == 63) {
         out_nhits[it.out_slot] = n;
-        out_found[it.out_slot] = (uint64_t)found + (uint64_t)found_s;
+        out_found[it.out_slot] = (uint64_t)found_s;
     }
 #ifdef NS_COUNT
     cnt_[17] = __builtin_readcyclecounter() - cyc_t0_;

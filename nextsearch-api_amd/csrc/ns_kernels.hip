@@ -537,6 +537,14 @@ __global__ void __launch_bounds__(256) k_merge(const DevQuery* __restrict__ quer
             }
             out_hits[(uint64_t)q * K + lane] = h;
         }
+        // a query WITHOUT work items (no scored term: pc == 0) takes this path with any K: the rest of its row is padding too
+        for (uint32_t i = 64u + (uint32_t)lane; i < K; i += 64u) {
+            Hit h;
+            h.score = -__builtin_inff();
+            h.seg = 0xFFFFFFFFu;
+            h.doc = 0xFFFFFFFFu;
+            out_hits[(uint64_t)q * K + i] = h;
+        }
         if (lane == 0) {
             out_nhits[q] = produced;
             out_found[q] = found;

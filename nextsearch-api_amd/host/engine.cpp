@@ -6,6 +6,7 @@
 #include <thread>
 #include <cmath>
 #include <limits>
+#include <cstring>
 
 #include "json_writer.hpp"
 #include "textutil.hpp"
@@ -56,6 +57,10 @@ static bool upload_segment(ns_ctx* ctx, uint32_t seg_id, nsx::SegmentData& s, ns
     }
     // skip tables for the segment's frequent lists (ns_segment_build_skips: 4 B per list and 1024-doc cell).  The
     // reference's lists carry no block metadata (src/lexicon.cpp:104-128); this is built from the uploaded postings.
+    // The tables are an accelerator, never a load precondition: the reference loads a segment with a damaged lexicon
+    // record and only the queries naming that term go wrong (src/api_engine.cpp:464-476), so records that do not
+    // describe a whole list inside the payload are left out here, and a refusal of the rest costs the tables, not the
+    // segment (queries then take the cursor path; a term ref of a damaged record is rejected at prepare, as before).
     {
         const uint32_t min_count = std::max<uint32_t>(64u, s.N / 512u);
         std::vector<uint64_t> off;
@@ -63,17 +68,13 @@ static bool upload_segment(ns_ctx* ctx, uint32_t seg_id, nsx::SegmentData& s, ns
         for (const auto& kv : s.lex) {
             const nsx::LexEntry& e = kv.second;
             if (e.df == 0 || e.count < min_count) continue;
-            off.push_back(s.list_byte_offset(e));
+            if (s.use_barrels && e.barrelId >= s.barrel_base.size()) continue;
+            const uint64_t bo = s.list_byte_offset(e);
+            if (bo % 8 != 0 || bo / 8 + e.count > s.postings_bytes / 8) continue;
+            off.push_back(bo);
             cnt.push_back(e.count);
         }
-        if (!off.empty()) {
-            rc = ns_segment_build_skips(ctx, dev, off.data(), cnt.data(), (uint32_t)off.size());
-            if (rc != NS_OK) {
-                err = std::string("ns_segment_build_skips: ") + ns_last_error(ctx);
-                (void)ns_segment_release(ctx, dev);
-                return false;
-            }
-        }
+        if (!off.empty()) (void)ns_segment_build_skips(ctx, dev, off.data(), cnt.data(), (uint32_t)off.size());
     }
     *out = dev;
     return true;
@@ -156,6 +157,7 @@ bool Engine::reload() {
     segments = std::move(loaded);
     meta = std::move(fresh_meta);
     sem = std::move(fresh_sem);
+    dict.build(segments, [](uint32_t N, uint32_t df) { return bm25_idf(N, df); });
     cache_.clear();
     lru_.clear();
     raw_postings_.clear();
@@ -231,10 +233,12 @@ void Engine::use_skips(bool on) { std::lock_guard<std::recursive_mutex> lock(mtx
 void Engine::use_impacts(bool on) { std::lock_guard<std::recursive_mutex> lock(mtx_); if (ctx_) ns_ctx_use_impacts(ctx_, on ? 1 : 0); }
 
 // Query preparation (tokenise, stop-words, lexicon probes, idf: src/api_engine.cpp:388-397,:454-461) for
-// queries [q0, q1); `refs` receives the term refs of those queries, qd[q].term_begin is relative to it.
+// queries [q0, q1) with GIVEN weighted terms (semantic expansion): `refs` receives the term refs of those queries,
+// qd[q].term_begin is relative to it.  Terms are probed in the dictionary, once per term for all segments.
 void Engine::build_refs_range(const std::vector<std::string>& queries, size_t q0, size_t q1, std::vector<ns_query_desc>& qd,
                               std::vector<ns_term_ref>& refs, std::vector<uint8_t>& usable,
                               const std::vector<nsx::WeightedTerms>* expanded) const {
+    std::vector<int64_t> gid;
     for (size_t q = q0; q < q1; q++) {
         nsx::WeightedTerms own;
         if (!expanded)   // weights: 1.0f per base term (src/api_engine.cpp:419-421)
@@ -243,25 +247,89 @@ void Engine::build_refs_range(const std::vector<std::string>& queries, size_t q0
         qd[q].term_begin = (uint32_t)refs.size();
         if (terms.empty() || segments.empty()) continue;   // src/api_engine.cpp:407, :424
         usable[q] = 1;
+        gid.clear();
+        for (const auto& tw : terms) gid.push_back(dict.find(tw.first.data(), tw.first.size()));
         for (uint32_t sid = 0; sid < segments.size(); sid++) {
-            const auto& seg = segments[sid];
-            for (const auto& tw : terms) {
-                const std::string& t = tw.first;
-                auto it = seg.lex.find(t);
-                if (it == seg.lex.end()) continue;           // :455
-                const nsx::LexEntry& e = it->second;
-                if (e.df == 0) continue;                      // :458
+            for (size_t ti = 0; ti < terms.size(); ti++) {
+                if (gid[ti] < 0) continue;                    // :455
+                const nsx::TermSeg& e = dict.row((uint32_t)gid[ti])[sid];
+                if (e.byte_off == nsx::kAbsent) continue;     // :455 / :458
                 ns_term_ref r;
                 r.seg_id = sid;
                 r.count = e.count;
-                r.byte_off = seg.list_byte_offset(e);
-                r.idf = bm25_idf(seg.N, e.df);
-                r.qweight = tw.second;
+                r.byte_off = e.byte_off;
+                r.idf = e.idf;
+                r.qweight = terms[ti].second;
                 refs.push_back(r);
             }
         }
         qd[q].term_count = (uint32_t)refs.size() - qd[q].term_begin;
     }
+}
+
+// The same for plain base terms (weight 1.0f, src/api_engine.cpp:419-421) straight from the query bytes: no std::string
+// per token, one dictionary probe per term, the per-segment numbers read from the term's row.
+void Engine::build_refs_views(const QueryView* queries, size_t q0, size_t q1, ns_query_desc* qd, std::vector<ns_term_ref>& refs,
+                              uint8_t* usable, std::vector<char>& scratch, std::vector<uint32_t>& gids) const {
+    const uint32_t S = (uint32_t)segments.size();
+    for (size_t q = q0; q < q1; q++) {
+        ns_query_desc& d = qd[q - q0];
+        d.term_begin = (uint32_t)refs.size();
+        d.term_count = 0;
+        gids.clear();
+        size_t n_terms = 0;
+        nsx::for_each_base_term(queries[q].p, queries[q].n, scratch, [&](const char* p, size_t n) {
+            n_terms++;
+            const int64_t g = dict.find(p, n);
+            if (g >= 0) gids.push_back((uint32_t)g);
+        });
+        usable[q - q0] = (n_terms != 0 && S != 0) ? 1 : 0;   // src/api_engine.cpp:407: no base terms (or no segments) -> early return
+        if (!usable[q - q0]) continue;
+        for (uint32_t sid = 0; sid < S; sid++) {
+            for (const uint32_t g : gids) {
+                const nsx::TermSeg& e = dict.row(g)[sid];
+                if (e.byte_off == nsx::kAbsent) continue;
+                refs.push_back(ns_term_ref{sid, e.count, e.byte_off, e.idf, 1.0f});
+            }
+        }
+        d.term_count = (uint32_t)refs.size() - d.term_begin;
+    }
+}
+
+unsigned Engine::prep_width(size_t Q) const {
+    unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+    return (unsigned)std::max<size_t>(1, std::min<size_t>(nt, Q / 256));   // below ~256 queries per thread the hand-over costs more than it saves
+}
+
+// queries [q0, q1) on the engine's host threads (contiguous slices; the dictionary is read-only), the slices' term refs
+// concatenated in query order.  qd / usable are indexed from q0.
+void Engine::build_refs_parallel(const QueryView* queries, size_t q0, size_t q1, std::vector<ns_query_desc>& qd,
+                                 std::vector<ns_term_ref>& refs, uint8_t* usable) const {
+    const size_t Q = q1 - q0;
+    qd.resize(Q);
+    refs.clear();
+    const unsigned nt = prep_width(Q);
+    if (scratch_.size() < nt) scratch_.resize(nt);
+    if (nt <= 1) {
+        build_refs_views(queries, q0, q1, qd.data(), refs, usable, scratch_[0].text, scratch_[0].gids);
+        return;
+    }
+    if (!pool_ || pool_->width() < nt) pool_.reset(new ForkJoin(std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u)));
+    pool_->run(nt, [&](unsigned i) {
+        PrepScratch& sc = scratch_[i];
+        sc.refs.clear();
+        const size_t a = q0 + Q * i / nt, b = q0 + Q * (i + 1) / nt;
+        build_refs_views(queries, a, b, qd.data() + (a - q0), sc.refs, usable + (a - q0), sc.text, sc.gids);
+    });
+    size_t total = 0;
+    std::vector<size_t> base(nt);
+    for (unsigned i = 0; i < nt; i++) { base[i] = total; total += scratch_[i].refs.size(); }
+    refs.resize(total);
+    pool_->run(nt, [&](unsigned i) {
+        const size_t a = Q * i / nt, b = Q * (i + 1) / nt;
+        for (size_t q = a; q < b; q++) qd[q].term_begin += (uint32_t)base[i];
+        if (!scratch_[i].refs.empty()) std::memcpy(refs.data() + base[i], scratch_[i].refs.data(), scratch_[i].refs.size() * sizeof(ns_term_ref));
+    });
 }
 
 // A batch is Q independent searches: large batches are prepared by several host
@@ -275,28 +343,15 @@ void Engine::build_refs(const std::vector<std::string>& queries, std::vector<ns_
     usable.assign(Q, 0);
     refs.clear();
     refs_failed_ = false;
-    std::vector<nsx::WeightedTerms> expanded;
-    const std::vector<nsx::WeightedTerms>* ex = nullptr;
     if (sem.enabled) {   // src/api_engine.cpp:409-417: one device call per top-k size for the whole batch
+        std::vector<nsx::WeightedTerms> expanded;
         if (!expand_queries(queries, expanded)) { refs_failed_ = true; return; }
-        ex = &expanded;
+        build_refs_range(queries, 0, Q, qd, refs, usable, &expanded);
+        return;
     }
-    unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
-    nt = (unsigned)std::min<size_t>(nt, Q / 512);   // below ~512 queries per thread the spawn costs more than it saves
-    if (nt <= 1) { build_refs_range(queries, 0, Q, qd, refs, usable, ex); return; }
-    std::vector<std::vector<ns_term_ref>> part(nt);
-    std::vector<std::thread> th;
-    for (unsigned i = 0; i < nt; i++)
-        th.emplace_back([&, i]() { build_refs_range(queries, Q * i / nt, Q * (i + 1) / nt, qd, part[i], usable, ex); });
-    for (auto& t : th) t.join();
-    size_t total = 0;
-    for (auto& p : part) total += p.size();
-    refs.reserve(total);
-    for (unsigned i = 0; i < nt; i++) {
-        const uint32_t base = (uint32_t)refs.size();
-        for (size_t q = Q * i / nt; q < Q * (i + 1) / nt; q++) qd[q].term_begin += base;
-        refs.insert(refs.end(), part[i].begin(), part[i].end());
-    }
+    std::vector<QueryView> views(Q);
+    for (size_t q = 0; q < Q; q++) views[q] = QueryView{queries[q].data(), queries[q].size()};
+    build_refs_parallel(views.data(), 0, Q, qd, refs, usable.data());
 }
 
 bool Engine::expand_queries(const std::vector<std::string>& queries, std::vector<nsx::WeightedTerms>& out) const {
@@ -332,21 +387,83 @@ bool Engine::search_batch(const std::vector<std::string>& queries, int k, uint32
     return search_batch_locked(queries, k, flags, out);
 }
 
+// Sub-batches of a large batch (search_batch_flat): big enough to keep the device near its full-batch rate (a 4096-query
+// batch of the cfg5 law runs at 85 % of a 16384-query batch's rate), small enough that preparing the first
+// one — the only host work the device does not hide — is a small part of the call.
+static constexpr size_t kSubBatch = 4096;
+
+bool Engine::search_batch_flat(const QueryView* queries, size_t Q, int k, uint32_t flags, ns_hit* hits, uint32_t* nhits,
+                               uint64_t* found, uint8_t* usable) {
+    std::lock_guard<std::recursive_mutex> lock(mtx_);
+    if (!ctx_) { err_ = "no device context: this engine has no CPU scoring path"; return false; }
+    if (Q && (!queries || !hits || !nhits || !found || !usable)) { err_ = "search_batch_flat: null argument"; return false; }
+    const int K = std::max(1, std::min(k, 100));   // src/api_engine.cpp:377
+    if (Q == 0) return true;
+    if (sem.enabled) {
+        // semantic expansion runs the whole batch through two device calls first (src/api_engine.cpp:409-417): not pipelined
+        std::vector<std::string> qs(Q);
+        for (size_t q = 0; q < Q; q++) qs[q].assign(queries[q].p, queries[q].n);
+        std::vector<ns_query_desc> qd;
+        std::vector<ns_term_ref> refs;
+        std::vector<uint8_t> us;
+        build_refs(qs, qd, refs, us);
+        if (refs_failed_) return false;
+        std::memcpy(usable, us.data(), Q);
+        int rc = ns_search_batch(ctx_, qd.data(), refs.data(), (uint32_t)Q, (uint32_t)K, hits, nhits, found, flags);
+        if (rc != NS_OK) { err_ = std::string("ns_search_batch: ") + ns_last_error(ctx_); return false; }
+        return true;
+    }
+    // two or more sub-batches: prepare(i + 1) on the host || kernels(i) on the device || results(i - 1) on their way back
+    const size_t n_sub = Q >= 2 * kSubBatch ? (Q + kSubBatch - 1) / kSubBatch : 1;
+    const bool piped = n_sub > 1;
+    if (piped) (void)ns_ctx_set_overlap(ctx_, 1);
+    struct InFlight { ns_batch* b = nullptr; size_t q0 = 0; };
+    InFlight prev;
+    bool ok = true;
+    auto retire = [&](InFlight& f) {
+        if (!f.b) return;
+        if (ok) {
+            const int rc = ns_batch_fetch(f.b, hits + f.q0 * (size_t)K, nhits + f.q0, found + f.q0);
+            if (rc != NS_OK) { err_ = std::string("ns_batch_fetch: ") + ns_last_error(ctx_); ok = false; }
+        }
+        ns_batch_destroy(f.b);
+        f.b = nullptr;
+    };
+    std::vector<ns_query_desc>& qd = flat_qd_;
+    std::vector<ns_term_ref>& refs = flat_refs_;
+    for (size_t i = 0; i < n_sub && ok; i++) {
+        const size_t q0 = Q * i / n_sub, q1 = Q * (i + 1) / n_sub;
+        build_refs_parallel(queries, q0, q1, qd, refs, usable + q0);
+        InFlight cur;
+        cur.q0 = q0;
+        int rc = ns_batch_prepare(ctx_, qd.data(), refs.data(), (uint32_t)(q1 - q0), (uint32_t)K, flags, &cur.b);
+        if (rc == NS_OK) rc = ns_batch_run(cur.b, NS_RUN_FETCH);
+        if (rc != NS_OK) {
+            err_ = std::string("ns_batch_prepare/run: ") + ns_last_error(ctx_);
+            ok = false;
+            if (cur.b) ns_batch_destroy(cur.b);
+            break;
+        }
+        retire(prev);     // waits for sub-batch i - 1 only; sub-batch i is already queued behind it
+        prev = cur;
+    }
+    retire(prev);
+    if (piped) (void)ns_ctx_set_overlap(ctx_, 0);
+    return ok;
+}
+
 bool Engine::search_batch_locked(const std::vector<std::string>& queries, int k, uint32_t flags, std::vector<SearchResult>& out) {
     out.clear();
     if (!ctx_) { err_ = "no device context: this engine has no CPU scoring path"; return false; }
     const int K = std::max(1, std::min(k, 100));
     const size_t Q = queries.size();
-    std::vector<ns_query_desc> qd;
-    std::vector<ns_term_ref> refs;
-    std::vector<uint8_t> usable;
-    build_refs(queries, qd, refs, usable);
-    if (refs_failed_) return false;
+    std::vector<QueryView> views(Q);
+    for (size_t q = 0; q < Q; q++) views[q] = QueryView{queries[q].data(), queries[q].size()};
     std::vector<ns_hit> hits(Q * (size_t)K);
     std::vector<uint32_t> nhits(Q);
     std::vector<uint64_t> found(Q);
-    int rc = ns_search_batch(ctx_, qd.data(), refs.data(), (uint32_t)Q, (uint32_t)K, hits.data(), nhits.data(), found.data(), flags);
-    if (rc != NS_OK) { err_ = std::string("ns_search_batch: ") + ns_last_error(ctx_); return false; }
+    std::vector<uint8_t> usable(Q);
+    if (!search_batch_flat(views.data(), Q, k, flags, hits.data(), nhits.data(), found.data(), usable.data())) return false;
     out.resize(Q);
     for (size_t q = 0; q < Q; q++) {
         SearchResult& r = out[q];

@@ -25,6 +25,8 @@
 #include "index_format.hpp"
 #include "metadata.hpp"
 #include "semantic.hpp"
+#include "term_dict.hpp"
+#include "../csrc/ns_forkjoin.hpp"
 
 namespace nextsearch {
 
@@ -53,6 +55,9 @@ public:
     std::vector<nsx::SegmentData> segments;
     nsx::MetadataTable meta;   // <index>/metadata.csv, parsed once at reload() (src/api_engine.cpp:110-113,:516-531)
     nsx::SemanticTable sem;    // optional embeddings (src/api_engine.cpp:115-153): when loaded, every search expands its terms (:409-417)
+    // term -> per-segment {byte_off, count, idf}, built at reload() next to the lexicons (term_dict.hpp):
+    // the one probe per query term that replaces the reference's per-(term, segment) seg.lex.find + bm25_idf (:454-461)
+    nsx::TermDict dict;
 
     // device < 0: host-only (index + query preparation; every search call fails loudly)
     explicit Engine(int device = 0);
@@ -80,6 +85,14 @@ public:
     static constexpr size_t kMaxCacheSize = 2600;               // include/api_engine.hpp:42
     bool search_hits(const std::string& query, int k, uint32_t flags, SearchResult& out);
     bool search_batch(const std::vector<std::string>& queries, int k, uint32_t flags, std::vector<SearchResult>& out);
+    // The same batch with flat, caller-owned outputs in the C-ABI's layout — hits Q x K (unused tail entries {-inf, ~0, ~0}),
+    // nhits[Q], found[Q], usable[Q] (0 = the early return of src/api_engine.cpp:407: no "found") — and no per-query
+    // allocation.  A large batch is cut into sub-batches that are pipelined on the one device context: the host prepares
+    // sub-batch i+1 (tokenise, dictionary probes) while the device scores sub-batch i (include/nextsearch_hip.h:
+    // NS_RUN_FETCH).  A batch == Q independent searches, so the cut changes no result.
+    struct QueryView { const char* p; size_t n; };
+    bool search_batch_flat(const QueryView* queries, size_t Q, int k, uint32_t flags, ns_hit* hits, uint32_t* nhits,
+                           uint64_t* found, uint8_t* usable);
 
     // Query preparation only: flattened term refs in the C-ABI's layout.
     // usable[q] == 0 marks the early-return case (no base terms, or no segments).
@@ -118,6 +131,19 @@ private:
     std::unordered_map<std::string, CacheEntry> cache_;
     std::list<std::string> lru_;   // most recently used at the front
     bool cache_on_ = true;
+    // query preparation of queries [q0, q1) through the term dictionary: refs appended to `refs`, qd[q - q0] filled with
+    // term_begin relative to `refs`' start, usable[q - q0] set
+    void build_refs_views(const QueryView* queries, size_t q0, size_t q1, ns_query_desc* qd, std::vector<ns_term_ref>& refs,
+                          uint8_t* usable, std::vector<char>& scratch, std::vector<uint32_t>& gids) const;
+    // host threads of query preparation (kept from batch to batch) and their scratch
+    struct PrepScratch { std::vector<ns_term_ref> refs; std::vector<char> text; std::vector<uint32_t> gids; };
+    mutable std::unique_ptr<ForkJoin> pool_;
+    mutable std::vector<PrepScratch> scratch_;
+    std::vector<ns_query_desc> flat_qd_;     // search_batch_flat's descriptor buffers, kept from call to call
+    std::vector<ns_term_ref> flat_refs_;
+    unsigned prep_width(size_t Q) const;
+    void build_refs_parallel(const QueryView* queries, size_t q0, size_t q1, std::vector<ns_query_desc>& qd,
+                             std::vector<ns_term_ref>& refs, uint8_t* usable) const;
     mutable bool refs_failed_ = false;   // build_refs could not run the device part of the expansion (err_ says why)
     int device_;
     ns_ctx* ctx_ = nullptr;

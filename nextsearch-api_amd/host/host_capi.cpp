@@ -238,22 +238,23 @@ extern "C" void nsh_free(void* p) { std::free(p); }
 extern "C" int nsh_engine_search_batch(nsh_engine* e, const char* const* queries, uint32_t n_queries, int k, uint32_t flags,
                                        ns_hit* hits, uint32_t* nhits, uint64_t* found, uint8_t* has_found) { try {
     if (!e) return -1;
-    std::vector<nextsearch::SearchResult> res;
-    if (!e->eng.search_batch(to_vec(queries, n_queries), k, flags, res)) { e->err = e->eng.last_error(); return -1; }
+    // Engine::search_batch_flat: the caller's arrays are the outputs; whichever the caller left out is kept in scratch
     const uint32_t K = (uint32_t)std::max(1, std::min(k, 100));
+    std::vector<nextsearch::Engine::QueryView> views(n_queries);
+    for (uint32_t q = 0; q < n_queries; q++) views[q] = {queries[q] ? queries[q] : "", queries[q] ? std::strlen(queries[q]) : 0};
+    std::vector<ns_hit> h_;
+    std::vector<uint32_t> n_;
+    std::vector<uint64_t> f_;
+    std::vector<uint8_t> u_;
+    if (!hits) { h_.resize((size_t)n_queries * K); hits = h_.data(); }
+    if (!nhits) { n_.resize(n_queries); nhits = n_.data(); }
+    if (!found) { f_.resize(n_queries); found = f_.data(); }
+    if (!has_found) { u_.resize(n_queries); has_found = u_.data(); }
+    if (!e->eng.search_batch_flat(views.data(), n_queries, k, flags, hits, nhits, found, has_found)) { e->err = e->eng.last_error(); return -1; }
     for (uint32_t q = 0; q < n_queries; q++) {
-        const auto& r = res[q];
-        if (nhits) nhits[q] = (uint32_t)r.hits.size();
-        if (found) found[q] = r.found;
-        if (has_found) has_found[q] = r.has_found ? 1 : 0;
-        if (hits) {
-            for (uint32_t i = 0; i < K; i++) {
-                ns_hit h;
-                if (i < r.hits.size()) { h.score = r.hits[i].score; h.seg_id = r.hits[i].seg; h.doc_id = r.hits[i].doc; }
-                else { h.score = -__builtin_inff(); h.seg_id = 0xFFFFFFFFu; h.doc_id = 0xFFFFFFFFu; }
-                hits[(size_t)q * K + i] = h;
-            }
-        }
+        if (has_found[q]) continue;   // the early return (src/api_engine.cpp:407): no hits, no found
+        nhits[q] = 0; found[q] = 0;
+        for (uint32_t i = 0; i < K; i++) hits[(size_t)q * K + i] = ns_hit{-__builtin_inff(), 0xFFFFFFFFu, 0xFFFFFFFFu};
     }
     return 0;
 } NSH_CATCH(e, "nsh_engine_search_batch", -1)

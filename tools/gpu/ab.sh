@@ -6,6 +6,8 @@ O=$R/gpurun_out/${1:-ab}
 LAWS=${2:-r1,cfg5_thin,cfg5_tile,cfg5_gen,cfg5,cfg3,cfg5_q2048}
 mkdir -p $O
 cd $R/nextsearch-api_amd && cp libnextsearch_hip.so libnextsearch_hip_new.so
+# the working tree's library is put back whatever happens (a failure mid-loop must not leave the base revision installed)
+trap 'cp $R/nextsearch-api_amd/libnextsearch_hip_new.so $R/nextsearch-api_amd/libnextsearch_hip.so' EXIT
 cd $R
 for rep in 1 2 3; do
   for v in base new; do
