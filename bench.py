@@ -70,6 +70,7 @@ def parse_args():
     ap.add_argument("--no-hbm-leg", action="store_true", help="skip the extra measurement over the 20-segment (HBM-resident) index")
     ap.add_argument("--hbm-segments", type=int, default=20)
     ap.add_argument("--hbm-queries", type=int, default=2048)
+    ap.add_argument("--hbm-only", action="store_true", help="profiling runs: ONLY the hbm_resident leg (prints its object as the JSON line)")
     ap.add_argument("--kernel-only", action="store_true", help="profiling runs: only the kernel leg (descriptors resident), no pipelined loop, no extra legs")
     return ap.parse_args()
 
@@ -142,6 +143,48 @@ def cpu_baselines(index_dir, queries, k, budget_s):
     return out[0], out
 
 
+def run_hbm_leg(args, nsbind, np, gen, seed, docs, K, flags, device, traffic_db):
+    """The same query law over an index that cannot sit in the 256 MiB Infinity Cache: S x 1M docs (every query scans all
+    S segments: S x the postings per query; 20 segments = 1.1 GB of postings + 0.55 GB of per-posting norms).  Kernel leg
+    only: descriptors resident, the scoring launch under HIP events."""
+    S, Qb = args.hbm_segments, args.hbm_queries
+    with tempfile.TemporaryDirectory(prefix="ns_bench_big_") as big:
+        bidx = os.path.join(big, "index")
+        nsbind.gen_index(bidx, S, docs, 65536, 1337, False)
+        beng = nsbind.Engine(bidx, device)
+        beng.set_tuning(args.variant, args.min_items, args.split)
+        bq = gen(Qb, seed)
+        bqd, brefs, _ = beng.build_refs(bq)
+        bb = nsbind.prepare_raw(beng.ctx, bqd, brefs, K, flags)
+        for _ in range(3):
+            bb.run(timed=False)
+        bb.sync()
+        n_big = max(5, args.steps // 2)
+        for _ in range(n_big):
+            bb.run(timed=True)
+        bb.sync()
+        binf = bb.info()
+        bh, bn, bf = bb.fetch()
+        assert (bn == np.minimum(bf, K)).all()
+        bb.close()
+        bms = binf.sum_score_kernel_ms / max(binf.timed_runs, 1)
+        bach = binf.algo_bytes / (bms * 1e-3) / 1e9
+        dev_bytes = sum(beng.segment_info(s)["n_postings"] for s in range(S)) * 12
+        tr = traffic_db.get(f"cfg5_big{S}_q{Qb}")
+        leg = {
+            "what": f"cfg5 query law, {Qb} queries over {S} segments x {docs} docs (every query scans every segment), kernel only",
+            "index_bytes_on_device": int(dev_bytes), "postings_per_query": binf.postings / max(Qb, 1), "work_items": binf.n_items,
+            "kernel_ms": bms, "queries_per_s_kernel": Qb / (bms * 1e-3), "timed_launches": int(binf.timed_runs),
+            "roofline": {"bound": "hbm", "achieved": bach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bach / HBM_PEAK_GBS,
+                         "algo_bytes_per_launch": int(binf.algo_bytes), "traffic": tr,
+                         "traffic_over_algo": (tr / binf.algo_bytes) if tr else None,
+                         "traffic_source": "L2-miss bytes per launch from the builder's rocprofv3 --pmc FETCH_SIZE pass of `bench.py --hbm-only` (x2 gfx950 correction), profiles/r03/final_hbm_leg_pmc_fetch.csv; not measured in this run",
+                         "limited_by": "instruction issue / memory latency, no longer bandwidth: with the XCD-aware launch order (items that share a list and a doc range meet in one L2) the launch moves ~1.3x its algorithmic bytes at ~4.6 TB/s of L2-miss traffic, below the ~6.3 TB/s this part streams at (round 2: 1.87x at 6.2 TB/s, saturated)"},
+        }
+        beng.close()
+        return leg
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -174,6 +217,17 @@ def main():
     L = nsbind.hip_lib()
 
     gen, q_default, K, flags, (nseg, docs) = workloads.WORKLOADS[args.config]
+    if args.hbm_only:
+        os.environ["NS_RELOAD_WARMUP"] = "0"
+        tdb = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                tdb = json.load(f)
+        except Exception:   # noqa: BLE001
+            pass
+        leg = run_hbm_leg(args, nsbind, np, gen, {"cfg2": 2002, "cfg3": 2003, "cfg4": 2004, "cfg5": 2005}[args.config], docs, K, flags, local_rank, tdb)
+        print(json.dumps({"hbm_resident": leg, "library": lib_info()}), flush=True)
+        return
     Q = args.queries or q_default                       # the global batch (strong) / the per-rank batch (weak)
     seed = {"cfg2": 2002, "cfg3": 2003, "cfg4": 2004, "cfg5": 2005}[args.config]
     strong = args.scaling == "strong" or n_gpus == 1
@@ -376,6 +430,38 @@ def main():
         b2.close()
         eng.use_impacts(False)
 
+    # block-max pruning: the same batch with the single-term queries skipping the blocks that cannot enter
+    # their top-K.  Reported next to the headline, never as `value` or `roofline`: those stay on the exhaustive path, where
+    # "algorithmic bytes" are bytes actually scanned.
+    pruned_leg = None
+    if n_gpus == 1 and args.variant == 0 and not args.no_impact_leg and not args.kernel_only and flags == 0:
+        t0 = time.perf_counter()
+        eng.build_blockmax()
+        build_s = time.perf_counter() - t0
+        eng.use_pruning(True)
+        b3 = nsbind.prepare_raw(eng.ctx, qd, refs, K, flags)
+        for _ in range(args.warmup):
+            b3.run(timed=False)
+        b3.sync()
+        for _ in range(args.steps):
+            b3.run(timed=True)
+        b3.sync()
+        inf3 = b3.info()
+        p_hits, p_nhits, p_found = b3.fetch()
+        same = p_hits.tobytes() == k_hits.tobytes() and p_nhits.tobytes() == k_nhits.tobytes() and p_found.tobytes() == k_found.tobytes()
+        assert inf3.flags & nsbind.NS_INFO_PRUNED, "the pruned leg did not take the block-max body"
+        assert same, "pruned results differ from the exhaustive path"
+        k3 = inf3.sum_score_kernel_ms / max(inf3.timed_runs, 1)
+        single = int((np.asarray(qd["term_count"]) == nseg).sum()) if nseg == 1 else None
+        pruned_leg = {
+            "what": "same batch, kernel only; single-term queries (found = the list's posting count) skip the 256-posting blocks whose maximum cannot enter their top-K; all other queries exhaustive",
+            "kernel_ms": k3, "queries_per_s_kernel": Qr / (k3 * 1e-3) if k3 > 0 else 0.0,
+            "single_term_queries": single, "build_s": build_s, "identical_results": same,
+            "note": "not a roofline number: the bytes of skipped blocks are never read",
+        }
+        b3.close()
+        eng.use_pruning(False)
+
     traffic_db = {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -387,42 +473,7 @@ def main():
 
     hbm_leg = None
     if n_gpus == 1 and args.config == "cfg5" and not args.no_hbm_leg and not args.kernel_only:
-        # The same query law over an index that cannot sit in the 256 MiB Infinity Cache: S x 1M docs (every query scans all
-        # S segments: S x the postings per query; 20 segments = 1.1 GB of postings + 0.55 GB of per-posting norms).
-        S, Qb = args.hbm_segments, args.hbm_queries
-        with tempfile.TemporaryDirectory(prefix="ns_bench_big_") as big:
-            bidx = os.path.join(big, "index")
-            nsbind.gen_index(bidx, S, docs, 65536, 1337, False)
-            beng = nsbind.Engine(bidx, local_rank)
-            beng.set_tuning(args.variant, args.min_items, args.split)
-            bq = gen(Qb, seed)
-            bqd, brefs, _ = beng.build_refs(bq)
-            bb = nsbind.prepare_raw(beng.ctx, bqd, brefs, K, flags)
-            for _ in range(3):
-                bb.run(timed=False)
-            bb.sync()
-            n_big = max(5, args.steps // 2)
-            for _ in range(n_big):
-                bb.run(timed=True)
-            bb.sync()
-            binf = bb.info()
-            bh, bn, bf = bb.fetch()
-            assert (bn == np.minimum(bf, K)).all()
-            bb.close()
-            bms = binf.sum_score_kernel_ms / max(binf.timed_runs, 1)
-            bach = binf.algo_bytes / (bms * 1e-3) / 1e9
-            dev_bytes = sum(beng.segment_info(s)["n_postings"] for s in range(S)) * 12
-            tr = traffic_db.get(f"cfg5_big{S}_q{Qb}")
-            hbm_leg = {
-                "what": f"cfg5 query law, {Qb} queries over {S} segments x {docs} docs (every query scans every segment), kernel only",
-                "index_bytes_on_device": int(dev_bytes), "postings_per_query": binf.postings / max(Qb, 1), "work_items": binf.n_items,
-                "kernel_ms": bms, "queries_per_s_kernel": Qb / (bms * 1e-3),
-                "roofline": {"bound": "hbm", "achieved": bach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bach / HBM_PEAK_GBS,
-                             "algo_bytes_per_launch": int(binf.algo_bytes), "traffic": tr,
-                             "traffic_source": "L2-miss bytes per launch from the builder's rocprofv3 --pmc FETCH_SIZE pass of this leg (x2 gfx950 correction), profiles/r02; not measured in this run",
-                             "limited_by": "memory: the launch moves ~2x its algorithmic bytes (12 B per posting by design + re-read partial rounds) at ~6 TB/s of L2-miss traffic, the rate streaming kernels reach on this part (~6.3 TB/s)"},
-            }
-            beng.close()
+        hbm_leg = run_hbm_leg(args, nsbind, np, gen, seed, docs, K, flags, local_rank, traffic_db)
 
     if rank == 0:
         achieved = kinfo.algo_bytes / (score_ms * 1e-3) / 1e9 if score_ms > 0 else 0.0
@@ -489,6 +540,8 @@ def main():
             line["hbm_resident"] = hbm_leg
         if impact_leg is not None:
             line["impact_stream"] = impact_leg
+        if pruned_leg is not None:
+            line["pruned"] = pruned_leg
         print(json.dumps(line), flush=True)
 
     eng.close()

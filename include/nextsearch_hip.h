@@ -41,6 +41,7 @@ extern "C" {
 #define NS_FLAG_AND     1u   /* extension (BASELINE config 2): keep docs matched by every term ref of their segment */
 #define NS_INFO_IMPACTS 0x100u /* ns_batch_info.flags only (output): the batch reads impact streams (ns_segment_build_impacts) */
 #define NS_INFO_PACKED  0x200u /* ns_batch_info.flags only (output): the batch's driver streams read the packed posting blocks (ns_segment_build_packed) */
+#define NS_INFO_PRUNED  0x400u /* ns_batch_info.flags only (output): some single-term queries of the batch skip posting blocks by their block maxima (ns_ctx_use_pruning) */
 
 typedef struct ns_ctx   ns_ctx;
 typedef struct ns_seg   ns_seg;
@@ -172,6 +173,22 @@ int ns_ctx_use_impacts(ns_ctx* ctx, int on);
 int ns_segment_build_skips(ns_ctx* ctx, ns_seg* seg, const uint64_t* byte_off, const uint32_t* counts, uint32_t n_lists);
 /* on = 0: batches prepared from now on ignore skip tables (default: on = 1). */
 int ns_ctx_use_skips(ns_ctx* ctx, int on);
+/* Block-max scores with `found`-exact pruning.  The reference reads every posting of every scored list
+ * (src/api_engine.cpp:470-481) because `found` (:495) is the size of the union of the lists' docs.  For a query whose term
+ * group in a segment is ONE list that size needs no reading: it is the number of the list's postings (every posting is a
+ * doc of its own), and the group's top-K (:485-492) only needs the blocks whose best score can still enter it.
+ * ns_segment_build_blockmax stores, for every list given, per 256 postings of the LIST the largest term score
+ * (idf * (tf * (k1 + 1))) / (tf + k1*((1-b) + b*dl/avgdl)) — src/api_engine.cpp:477-479 with the given idf, the same fp32
+ * operations as the scoring kernels (4 B per 256 postings, built on the device from the uploaded postings).  With
+ * ns_ctx_use_pruning(ctx, 1) (default 0: every posting is read, as the reference does, and that is what bench.py's `value`
+ * and `roofline` measure) a single-term group whose list is registered with the bit-identical idf and whose weight is
+ * positive visits its blocks in docId order and skips, unread, every block whose maximum times the weight is <= the score
+ * of its current K-th best (ties go to the smaller docId, which is already in).  hits, their order, nhits and found are
+ * bit-identical to the exhaustive path (tests run both ways).  Multi-term groups are not pruned: their `found` needs the
+ * lists merged.  byte_off/counts/idfs as in ns_term_ref; a list given again with another idf is rebuilt. */
+int ns_segment_build_blockmax(ns_ctx* ctx, ns_seg* seg, const uint64_t* byte_off, const uint32_t* counts,
+                              const float* idfs, uint32_t n_lists);
+int ns_ctx_use_pruning(ns_ctx* ctx, int on);
 
 /* ---- one-shot search (host buffers in, host buffers out) ------------------------------------ */
 /* hits_out: Q*K entries, query-major, best first: score desc, then seg_id asc, then doc_id asc
@@ -212,14 +229,6 @@ int  ns_batch_fetch(ns_batch* b, ns_hit* hits_out, uint32_t* nhits_out, uint64_t
 int  ns_batch_get_info(ns_batch* b, ns_batch_info* info);
 void ns_batch_destroy(ns_batch* b);
 
-/* ---- tuning knobs (per ctx; 0 = library default) --------------------------------------------- */
-/* variant: 0 = default (k_uscore: every work item picks the driver-stream or the doc-tile body);
- * 12..17 = driver-stream body for every group, 18..20 = doc-tile body for every group, 5..11 = the
- * previous wave-private kernel, 1..4 = the workgroup-tile kernel (also the fallback for term groups
- * of more than 64 terms); see DESIGN.md "Kernel variants" (all are parity-tested).  min_items: number
- * of work items below which groups are additionally split across doc ranges.  split_postings: a
- * (query, segment) group is split into doc ranges of about this much estimated work (variant 0: units
- * of one streamed posting, default 98304 for K <= 32 and 131072 above; other variants: postings). */
 /* Semantic query expansion's similarity search: SemanticIndex::most_similar_to_vec,
  * src/semantic_embedding.cpp:104-145.  ns_sem_upload takes the row-major table of L2-normalised fp32 vectors
  * (SemanticIndex::vecs, include/semantic_embedding.hpp:24).  ns_sem_topk: for each of n_q query vectors (host,
@@ -267,6 +276,16 @@ int ns_segment_upload_inverted(ns_ctx* ctx, ns_seg* seg, const uint32_t* doc_ter
                                uint64_t n_pairs, uint32_t n_terms, uint32_t* df_out, void* postings_out,
                                uint64_t* kept_out, float* device_ms_out);
 
+/* ---- tuning knobs (per ctx; 0 = library default) --------------------------------------------- */
+/* variant: 0 = the product's one scoring launch, k_uscore — every work item picks the driver-stream body, the doc-tile body
+ * or (ns_ctx_use_pruning) the block-max body; term groups of more than 64 terms fall back to the workgroup-tile kernel
+ * k_score.  libnextsearch_hip.so accepts variant 0 only.  The forced variants — 12..17 = the driver-stream body as a kernel
+ * of its own for every group (other table / foreign-budget sizes), 18..20 = the doc-tile body for every group (512 / 1024 /
+ * 2048-doc tiles), 1..4 = k_score for every group (four tile sizes) — are test and sweep infrastructure and exist in
+ * libnextsearch_hip_variants.so (`make -C nextsearch-api_amd variants`); 5..11 were retired in round 2 and are rejected by
+ * both builds.  min_items: number of work items below which groups are additionally split across doc ranges.
+ * split_postings: a (query, segment) group is split into doc ranges of about this much estimated work (variant 0: units of
+ * one streamed posting, default 98304 for K <= 32 and 131072 above; forced variants: postings). */
 int  ns_set_tuning(ns_ctx* ctx, uint32_t variant, uint32_t min_items, uint32_t split_postings);
 
 #ifdef __cplusplus

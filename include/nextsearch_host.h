@@ -26,6 +26,15 @@ int nsh_gen_index(const char* index_dir, uint32_t n_segments, uint32_t docs_per_
  * returns non-zero and *out still receives an engine whose nsh_engine_error() explains why
  * (free it with nsh_engine_close). */
 int  nsh_engine_open(const char* index_dir, int device, nsh_engine** out);
+/* The multi-device engine ("one host thread + ns_ctx per GPU"): the index is replicated on every device
+ * of devices[0 .. n_devices) (the same device may be listed twice: two contexts on one GPU), and nsh_engine_search_batch
+ * cuts a batch into contiguous shards of ceil(Q / n_devices) queries, one per device, each driven by its own host thread;
+ * the results land in the caller's one set of arrays.  devices[0] is the primary context (nsh_engine_ctx, single searches).
+ * Same failure convention as nsh_engine_open. */
+int  nsh_engine_open_multi(const char* index_dir, const int* devices, uint32_t n_devices, nsh_engine** out);
+uint32_t nsh_engine_num_devices(nsh_engine* e);
+/* [begin, end) of shard r of n over n_queries queries, as nsh_engine_search_batch cuts them (arithmetic only) */
+void nsh_shard_bounds(uint64_t n_queries, uint32_t r, uint32_t n, uint64_t* begin, uint64_t* end);
 void nsh_engine_close(nsh_engine* e);
 /* Engine::reload() again on the same directory.  0 on success.  On failure (non-zero) the engine keeps the index,
  * the device copy and the caches it had (the reference swaps its segments in only after every one loaded,
@@ -67,6 +76,11 @@ void nsh_engine_use_skips(nsh_engine* e, int on);
  * ns_ctx_use_packed): 4-7 B read per posting instead of 12, same results.  Not part of reload(): 8 B of HBM per posting. */
 int  nsh_engine_build_packed(nsh_engine* e);
 void nsh_engine_use_packed(nsh_engine* e, int on);
+/* Optional block maxima for every list of >= 512 postings of every loaded segment (include/nextsearch_hip.h:
+ * ns_segment_build_blockmax) and the switch for `found`-exact pruning of single-term queries (ns_ctx_use_pruning; off by
+ * default).  Same results either way. */
+int  nsh_engine_build_blockmax(nsh_engine* e);
+void nsh_engine_use_pruning(nsh_engine* e, int on);
 
 uint32_t nsh_engine_num_segments(nsh_engine* e);
 const char* nsh_engine_segment_name(nsh_engine* e, uint32_t seg);

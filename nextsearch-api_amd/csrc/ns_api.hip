@@ -23,6 +23,7 @@
 #include "ns_kernels.hip"
 #include "ns_wave_kernel.hip"
 #include "ns_driver_kernel.hip"
+#include "ns_prune_kernel.hip"
 #include "ns_tile_kernel.hip"
 #include "ns_invert.hip"
 #include "ns_sem.hip"
@@ -86,6 +87,22 @@ struct ns_seg {
             if (e.first == 0xFFFFFFFFu) return 0;
         }
     }
+    // Optional block maxima (ns_segment_build_blockmax; DevSeg::blockmax): per registered list ceil(count / 256) fp32 values.
+    float* d_blockmax = nullptr;
+    std::vector<float*> bmx_retired;         // outgrown blocks: batches prepared before the growth still point into them
+    uint64_t bmx_cap = 0, bmx_used = 0;      // entries allocated / in use
+    struct BmxList { uint32_t first = 0xFFFFFFFFu, count = 0, idf_bits = 0, entry = 0; };
+    std::vector<BmxList> bmx_tab;            // open-addressed, size a power of two (or 0)
+    // 1 + index of the first block maximum of the list [first, first + count) built with this idf, or 0
+    uint32_t bmx_of(uint32_t first, uint32_t count, uint32_t idf_bits) const {
+        if (bmx_tab.empty()) return 0;
+        const size_t mask = bmx_tab.size() - 1;
+        for (size_t h = ((size_t)first * 0x9E3779B1u) & mask;; h = (h + 1) & mask) {
+            const BmxList& e = bmx_tab[h];
+            if (e.first == first) return (e.count == count && e.idf_bits == idf_bits) ? e.entry + 1u : 0u;
+            if (e.first == 0xFFFFFFFFu) return 0;
+        }
+    }
     bool imp_has(uint32_t first, uint32_t count, uint32_t idf_bits) const {
         if (imp_tab.empty()) return false;
         const size_t mask = imp_tab.size() - 1;
@@ -138,6 +155,7 @@ struct ns_ctx {
     bool use_impacts = true;   // batches take the impact stream when every list they touch has one (ns_ctx_use_impacts)
     int use_packed = 1;        // 0 off; 1, 2: batches read the packed stream when every segment they touch has one (ns_ctx_use_packed)
     bool use_skips = true;     // doc-tile groups walk the skip grid when their lists have skip tables (ns_ctx_use_skips)
+    bool use_pruning = false;  // single-term groups whose list has block maxima skip the blocks that cannot enter the top-K (ns_ctx_use_pruning)
     ns_prep* prep = nullptr;   // ns_batch_prepare's host threads and per-thread scratch, kept from batch to batch
     unsigned prep_threads = 0; // 0 = automatic (up to 8); 1 = prepare on the calling thread only (ns_ctx_set_host_threads)
     // Launch order inside coarse run-time classes (see "XCD dealing" in ns_batch_prepare): 1 = on.  The environment variables
@@ -309,6 +327,12 @@ extern "C" const char* ns_device_name(ns_ctx* ctx) { return ctx ? ctx->devname.c
 extern "C" int ns_set_tuning(ns_ctx* ctx, uint32_t variant, uint32_t min_items, uint32_t split_postings) {
     if (!ctx) return fail(nullptr, NS_E_INVAL, "ns_set_tuning: ctx is NULL");
     if (variant >= kNumVariants || kVariants[variant].nt == 0) return fail(ctx, NS_E_INVAL, "unknown kernel variant %u", variant);
+#ifndef NS_VARIANTS
+    // The product library holds ONE scoring kernel (k_uscore, variant 0) plus k_score as the fallback for term groups of more
+    // than 64 terms.  The forced variants — each body as a kernel of its own, other table / tile sizes — exist for the
+    // parity tests and for sweeps: `make -C nextsearch-api_amd variants` builds libnextsearch_hip_variants.so with them.
+    if (variant != 0) return fail(ctx, NS_E_INVAL, "kernel variant %u exists only in the variants build (make -C nextsearch-api_amd variants)", variant);
+#endif
     ctx->variant = variant;
     ctx->min_items = min_items;
     ctx->split_postings = split_postings;
@@ -346,6 +370,10 @@ static void seg_free_device(ns_seg* s) {
     (void)hipFree(s->d_skips);
     for (uint32_t* p : s->skip_retired) (void)hipFree(p);
     s->skip_retired.clear();
+    (void)hipFree(s->d_blockmax);
+    for (float* p : s->bmx_retired) (void)hipFree(p);
+    s->bmx_retired.clear();
+    s->d_blockmax = nullptr; s->bmx_cap = s->bmx_used = 0; s->bmx_tab.clear();
     s->d_skips = nullptr; s->skip_cap = s->skip_used = 0; s->skip_tab.clear(); s->skip_lists = 0;
     s->d_postings = nullptr; s->d_norm = nullptr; s->d_pnorm = nullptr; s->d_impacts = nullptr; s->d_packed = nullptr;
     s->d_pk_hdr = nullptr; s->d_pk_scores = nullptr; s->d_nidx = nullptr; s->d_ntab = nullptr;
@@ -784,6 +812,94 @@ extern "C" int ns_segment_build_skips(ns_ctx* ctx, ns_seg* seg, const uint64_t* 
     return NS_OK;
 }
 
+// Block maxima of the given lists (DevSeg::blockmax; ns_prune_kernel.hip): per 256 postings of a list the largest BM25 term
+// score with the given idf.  Lists given again (same first posting) are rebuilt with the new idf; tables already built stay
+// where they are (batches prepared earlier hold indices into them).
+extern "C" int ns_segment_build_blockmax(ns_ctx* ctx, ns_seg* seg, const uint64_t* byte_off, const uint32_t* counts, const float* idfs, uint32_t n_lists) {
+    if (!ctx || !seg) return fail(ctx, NS_E_INVAL, "ns_segment_build_blockmax: null argument");
+    if (seg->pending || seg->id >= ctx->segs.size() || ctx->segs[seg->id] != seg) return fail(ctx, NS_E_INVAL, "segment does not belong to this ctx");
+    if (n_lists && (!byte_off || !counts || !idfs)) return fail(ctx, NS_E_INVAL, "null list arrays");
+    if (!n_lists || !seg->n_postings) return NS_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    struct L { uint32_t first, count; float idf; uint32_t entry; };
+    std::vector<L> lists;
+    lists.reserve(n_lists);
+    for (uint32_t i = 0; i < n_lists; i++) {
+        if (byte_off[i] % 8 != 0) return fail(ctx, NS_E_INVAL, "list %u: byte offset %llu is not a multiple of 8", i, (unsigned long long)byte_off[i]);
+        const uint64_t first = byte_off[i] / 8;
+        if (first + counts[i] > seg->n_postings) return fail(ctx, NS_E_INVAL, "list %u runs past the segment's postings", i);
+        uint32_t ib; std::memcpy(&ib, &idfs[i], 4);
+        if (counts[i] && !seg->bmx_of((uint32_t)first, counts[i], ib)) lists.push_back({(uint32_t)first, counts[i], idfs[i], 0u});
+    }
+    std::sort(lists.begin(), lists.end(), [](const L& a, const L& b) { return a.first < b.first; });
+    lists.erase(std::unique(lists.begin(), lists.end(), [](const L& a, const L& b) { return a.first == b.first; }), lists.end());
+    if (lists.empty()) return NS_OK;
+    uint64_t need = seg->bmx_used;
+    uint32_t bmax_blocks = 0;
+    for (auto& l : lists) {
+        const uint32_t nb = (l.count + kBmxBlock - 1) / kBmxBlock;
+        l.entry = (uint32_t)need;
+        need += nb;
+        bmax_blocks = std::max(bmax_blocks, nb);
+    }
+    if (need + 64 >= (1ull << 32) - 1) return fail(ctx, NS_E_INVAL, "ns_segment_build_blockmax: %llu entries do not fit 32 bits", (unsigned long long)need);
+    hipError_t e = hipSuccess;
+    if (need + 64 > seg->bmx_cap) {   // +64: a wave reads 64 maxima at a time, possibly past a list's last block
+        float* bigger = nullptr;
+        const uint64_t cap = std::max<uint64_t>(need + 64, seg->bmx_cap * 2);
+        e = hipMalloc((void**)&bigger, cap * 4);
+        if (e != hipSuccess) return fail(ctx, NS_E_NOMEM, "hipMalloc block maxima (%llu B): %s", (unsigned long long)(cap * 4), hipGetErrorString(e));
+        e = hipMemsetAsync(bigger, 0, cap * 4, ctx->stream);
+        if (e == hipSuccess && seg->d_blockmax) {
+            e = hipMemcpyAsync(bigger, seg->d_blockmax, seg->bmx_used * 4, hipMemcpyDeviceToDevice, ctx->stream);
+            seg->bmx_retired.push_back(seg->d_blockmax);
+        }
+        seg->d_blockmax = bigger;
+        seg->bmx_cap = cap;
+        if (e != hipSuccess) return fail(ctx, NS_E_HIP, "ns_segment_build_blockmax: %s", hipGetErrorString(e));
+    }
+    const size_t n = lists.size();
+    std::vector<uint32_t> h(n * 4);
+    for (size_t i = 0; i < n; i++) {
+        h[i] = lists[i].first; h[n + i] = lists[i].count;
+        std::memcpy(&h[2 * n + i], &lists[i].idf, 4);
+        h[3 * n + i] = lists[i].entry;
+    }
+    uint32_t* d_tmp = nullptr;
+    e = hipMalloc((void**)&d_tmp, n * 16);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_tmp, h.data(), n * 16, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        for (size_t l0 = 0; l0 < n; l0 += 32768) {   // grid.y is limited to 65535
+            const uint32_t ny = (uint32_t)std::min<size_t>(32768, n - l0);
+            hipLaunchKernelGGL(k_blockmax, dim3(std::min<uint32_t>(std::max<uint32_t>(bmax_blocks, 1u), 256u), ny), dim3(64), 0, ctx->stream,
+                               seg->d_postings, seg->d_pnorm, seg->d_blockmax, d_tmp + l0, d_tmp + n + l0, (const float*)(d_tmp + 2 * n + l0), d_tmp + 3 * n + l0);
+        }
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_tmp);
+    if (e != hipSuccess) return fail(ctx, NS_E_HIP, "ns_segment_build_blockmax: %s", hipGetErrorString(e));
+    seg->bmx_used = need;
+    std::vector<ns_seg::BmxList> all;
+    for (const auto& t : seg->bmx_tab) if (t.first != 0xFFFFFFFFu) all.push_back(t);
+    for (const auto& l : lists) { ns_seg::BmxList t; t.first = l.first; t.count = l.count; std::memcpy(&t.idf_bits, &l.idf, 4); t.entry = l.entry; all.push_back(t); }
+    size_t cap = 16;
+    while (cap < all.size() * 2) cap <<= 1;
+    std::vector<ns_seg::BmxList> tab(cap);
+    for (const auto& t : all)
+        for (size_t hh = ((size_t)t.first * 0x9E3779B1u) & (cap - 1);; hh = (hh + 1) & (cap - 1)) {
+            if (tab[hh].first == 0xFFFFFFFFu || tab[hh].first == t.first) { tab[hh] = t; break; }   // a list given again: the later table wins
+        }
+    seg->bmx_tab.swap(tab);
+    return NS_OK;
+}
+
+extern "C" int ns_ctx_use_pruning(ns_ctx* ctx, int on) {
+    if (!ctx) return NS_E_INVAL;
+    ctx->use_pruning = on != 0;
+    return NS_OK;
+}
+
 extern "C" int ns_ctx_use_skips(ns_ctx* ctx, int on) {
     if (!ctx) return NS_E_INVAL;
     ctx->use_skips = on != 0;
@@ -830,6 +946,7 @@ struct ns_batch {
     uint64_t postings = 0;
     bool direct = false;   // every query has exactly one work item: the scoring kernel writes final rows
     int pk = 0;            // every segment of the batch has a packed posting stream and the ctx wants it: 1 = packed docIds + tf, norms from the fp32 norm stream; 2 = norms through the 16-bit norm index (ns_ctx_use_packed)
+    bool pruned = false;   // some single-term items take the block-max pruned body (ns_ctx_use_pruning)
     bool imp = false;      // every list of the batch has an impact stream: the kernels read {docId, score} instead of {docId, tf} + norm
     // device
     DevItem* d_items = nullptr;
@@ -960,14 +1077,14 @@ struct PrepSlice {
     std::vector<uint32_t> qgroup_begin;   // q1 - q0 + 1 entries, local group indices
     std::vector<uint32_t> seg_ids;
     uint64_t bounds_total = 0, postings_total = 0, total_work = 0;
-    bool all_imp = true, all_pk = true;
+    bool all_imp = true, all_pk = true, any_pruned = false;
     int err_code = NS_OK;
     uint32_t err_query = 0xFFFFFFFFu;
     std::string err_msg;
     // phase B
     std::vector<DevWItem> witems;
     std::vector<uint16_t> wbucket;        // launch-order bucket of each wave item; bit 15: > 16 terms (the "wide" instantiation)
-    std::vector<uint16_t> wshare;         // 12-bit locality key of the item: (segment, eighth of the doc space) << 4 | hash of its largest list -> XCD dealing
+    std::vector<uint32_t> wshare;         // locality key of the item: segment (6 bits) | doc range on the 4096-grid (12) | hash of its largest list (14) -> XCD dealing
     std::vector<DevItem> items;
     std::vector<uint64_t> item_cost;
     std::vector<DevGroup> bgroups;
@@ -981,7 +1098,7 @@ struct PrepSlice {
     void reset(uint32_t a, uint32_t b) {
         q0 = a; q1 = b;
         dterms.clear(); groups.clear(); qgroup_begin.clear(); seg_ids.clear();
-        bounds_total = postings_total = total_work = 0; all_imp = true; all_pk = true;
+        bounds_total = postings_total = total_work = 0; all_imp = true; all_pk = true; any_pruned = false;
         err_code = NS_OK; err_query = 0xFFFFFFFFu; err_msg.clear();
         witems.clear(); wbucket.clear(); wshare.clear(); items.clear(); item_cost.clear(); bgroups.clear();
         n_rows = 0; direct = true;
@@ -1004,10 +1121,10 @@ struct PrepSlice {
 
 struct ns_prep {
     std::vector<PrepSlice> slices;
-    std::vector<uint16_t> share_at;       // per launch position: the item's locality key (XCD dealing)
+    std::vector<uint32_t> share_at;       // per launch position: the item's locality key (XCD dealing)
     std::vector<uint32_t> bucket_pos;     // launch position at which each fine bucket of the narrow half starts (+ the end)
     std::vector<std::vector<DevWItem>> deal_tmp;   // per host thread
-    std::vector<std::vector<uint32_t>> deal_pos;
+    std::vector<std::vector<uint64_t>> deal_key;
     ForkJoin* pool = nullptr;
     ~ns_prep() { delete pool; }
 };
@@ -1041,6 +1158,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
             d.ntab = s->d_ntab;
             d.pk_scores = s->d_pk_scores;
             d.skips = s->d_skips;
+            d.blockmax = s->d_blockmax;
             d.norm = s->d_norm;
             d.n_postings = s->n_postings;
             d.n_docs = s->n_docs;
@@ -1235,6 +1353,18 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                             if (dt[ti].skip) hg.grid = true;
                         }
                     }
+                    // Block-max pruning (ns_ctx_use_pruning): a group of ONE list whose block maxima were built with this idf, scored
+                    // with a positive weight — the fp32 product w * s is then monotone in s and never a negative zero
+                    bool pruned = false;
+                    if (auto_mode && ctx->use_pruning && hg.g.term_count == 1 && !ctx->segs[hg.g.seg]->bmx_tab.empty()) {
+                        DevTerm* dt = S.dterms.data() + (hg.g.term_begin - S.term_off);
+                        uint32_t ib; std::memcpy(&ib, &dt[0].idf, 4);
+                        if (dt[0].idf > 0.0f && std::isfinite(dt[0].idf) && dt[0].weight > 0.0f && std::isfinite(dt[0].weight)) {
+                            dt[0].bmx = ctx->segs[hg.g.seg]->bmx_of((uint32_t)dt[0].list_off, dt[0].count, ib);
+                            pruned = dt[0].bmx != 0;
+                        }
+                        if (pruned) S.any_pruned = true;
+                    }
                     // launch-order key = estimated run time of the ITEM: its share of the group's work plus what
                     // every item pays per term regardless of size (window planning, range searches, table set-up)
                     const uint64_t per_term = hg.cls == 2 ? kItemTermTile : (hg.cls == 1 ? kItemTermThin : kItemTermGeneral);
@@ -1272,15 +1402,16 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                         it.out_slot = S.n_rows++;
                         it.whole = (ns == 1 ? 1u : 0u) | (hg.fast_div ? 8u : 0u) | (hg.signed_in ? 16u : 0u) | (hg.grid ? (hg.cls == 2 ? 32u : 64u) : 0u);
                         // auto mode: very dense groups take the doc-tile body (bit 1), groups with thin non-driver lists the small foreign budget (bit 2)
-                        if (auto_mode) it.whole |= (hg.cls == 2 ? 2u : 0u) | (hg.cls == 1 ? 4u : 0u);
+                        if (auto_mode) it.whole |= (hg.cls == 2 ? 2u : 0u) | (hg.cls == 1 ? 4u : 0u) | (pruned ? 128u : 0u);
                         S.witems.push_back(it);
                         S.wbucket.push_back((uint16_t)(bucket | (wide ? 0x8000u : 0u)));
                         {
                             uint64_t h = big_off * 0x9E3779B97F4A7C15ull;
                             h ^= h >> 29;
-                            const uint32_t rr = (it.seg * 8u + (uint32_t)((uint64_t)it.doc_lo * 8u / std::max<uint32_t>(sg.n_docs, 1u))) & 255u;
-                            S.wshare.push_back((uint16_t)((rr << 4) | (uint32_t)(h & 15u)));
+                            const uint32_t r12 = (uint32_t)(((uint64_t)it.doc_lo << 12) / std::max<uint32_t>(sg.n_docs, 1u)) & 4095u;
+                            S.wshare.push_back(((it.seg & 63u) << 26) | (r12 << 14) | (uint32_t)((h >> 40) & 0x3FFFu));
                         }
+                        S.hist[(wide ? kOrderBuckets : 0) + bucket]++;
                     }
                 } else {
                     DevGroup g = hg.g;
@@ -1332,6 +1463,9 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
             if (half == 0) { n_class[0] = pos; P.bucket_pos[kOrderBuckets] = pos; }
         }
         n_class[1] = pos - n_class[0];
+        // every wave item has exactly one launch position (the kernels trust the item array: an item lost or doubled here
+        // would be a wild descriptor on the device)
+        if (pos != n_witems) return fail(ctx, NS_E_STATE, "internal: launch order holds %u of %u work items", pos, n_witems);
         if (!auto_mode) { n_class[0] = n_class[1] = 0; }
     }
     // the workgroup-kernel items (fallback path: few): longest first, serially
@@ -1368,6 +1502,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
     b->direct = direct;
     b->imp = all_imp && postings_total > 0;
     b->pk = (all_pk && postings_total > 0) ? ctx->use_packed : 0;
+    for (unsigned s2 = 0; s2 < width; s2++) b->pruned = b->pruned || P.slices[s2].any_pruned;
 
     // queries cut into many partial rows: joined by k_merge_wide, one workgroup each
     std::vector<uint32_t> wide_q;
@@ -1458,7 +1593,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
         std::vector<char> unstaged;
         if (!staged) unstaged.resize(up_bytes);
         char* hb = staged ? (char*)ctx->h_up : unstaged.data();
-        const bool deal = ctx->order_mode == 1 && auto_mode && n_class[0] >= 64;
+        const bool deal = ctx->order_mode >= 1 && auto_mode && n_class[0] >= 64;
         if (deal && P.share_at.size() < n_witems) P.share_at.resize(n_witems);
         fork([&](unsigned si) {
             PrepSlice& S = P.slices[si];
@@ -1478,46 +1613,37 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
         });
         // ---- XCD dealing.  The launch order is longest-estimated-run-time first (2048 fine buckets).  Inside a coarse class of
         // 8 fine buckets (run times within ~19 % of each other) the order is free, and it is used for locality: workgroup i
-        // runs on XCD i % 8, each XCD has its own 4 MB L2, and items that read the same bytes — same segment, same part of
-        // the doc space, same largest list: the shards of a hot list that dozens of queries of a batch share — should meet
+        // runs on XCD i % 8, each XCD has its own 4 MB L2, and items that read the same bytes — same segment, same doc range
+        // of the grid, same largest list: the shards of a hot list that dozens of queries of a batch share — should meet
         // in ONE L2 at about the same time, so that one of them pulls a line from HBM and the others hit it.  The items of a
-        // class are sorted by their 12-bit locality key (segment and eighth of the doc space first, then a hash of the
-        // largest list; counting sort, stable), the sorted sequence is cut into eight equal parts, and XCD x — the launch
-        // positions p with p % 8 == x — takes part x in order: one L2 per part of the doc space, neighbours in time share lists.
-        // Measured (profiles/r03): 20 x 1M-doc index, L2-miss traffic of the cfg5 launch 44.2 -> 30.9 GB, 7.24 -> 6.86 ms; the
-        // 1M-doc index 2.76 -> 2.67 ms.  O(items); the classes are spread over the prepare threads.
+        // class are sorted by their locality key (segment, then doc range, then a hash of the largest list), the sorted
+        // sequence is cut into eight equal parts, and XCD x — the launch positions p with p % 8 == x — takes part x in
+        // order: one L2 per part of the doc space, neighbours in time share lists.
+        // Measured (profiles/r03): 20 x 1M-doc index, L2-miss traffic of the cfg5 launch 44.2 -> 31 GB, 7.05 -> 6.70 ms; the
+        // 1M-doc index 2.61 -> 2.56 ms.  (A key quantised to eighths of the doc space lost 3 % there: the exact range matters.)
+        // The classes are spread over the prepare threads; a class of n items costs one sort of n 64-bit words.
         if (deal) {
             DevWItem* wd = (DevWItem*)(hb + o_witems);
             const uint32_t shift = (uint32_t)ctx->order_coarse;
             const uint32_t n_cls = kOrderBuckets >> shift;
-            if (P.deal_tmp.size() < width) { P.deal_tmp.resize(width); P.deal_pos.resize(width); }
+            if (P.deal_tmp.size() < width) { P.deal_tmp.resize(width); P.deal_key.resize(width); }
             fork([&](unsigned si) {
                 std::vector<DevWItem>& tmp = P.deal_tmp[si];
-                std::vector<uint32_t>& ord = P.deal_pos[si];   // [0, n): sorted order (original indices); [n, n + 4097): bins
+                std::vector<uint64_t>& ord = P.deal_key[si];   // (key << 32 | index in the class): sorted = stable by key
                 for (uint32_t c = si; c < n_cls; c += width) {
                     const uint32_t p0 = P.bucket_pos[c << shift], p1 = P.bucket_pos[(c + 1) << shift];
                     const uint32_t n = p1 - p0;
                     if (n < 16) continue;
-                    const uint16_t* key = P.share_at.data() + p0;
-                    if (n <= 2048) {   // few items: sort (key, index) words; many: counting sort over the 4096 keys (both stable)
-                        ord.resize(n);
-                        for (uint32_t i = 0; i < n; i++) ord[i] = ((uint32_t)(key[i] & 4095u) << 16) | i;
-                        std::sort(ord.begin(), ord.end());
-                        for (uint32_t i = 0; i < n; i++) ord[i] &= 0xFFFFu;
-                    } else {
-                        ord.assign((size_t)n + 4097, 0u);
-                        uint32_t* bins = ord.data() + n;
-                        for (uint32_t i = 0; i < n; i++) bins[(key[i] & 4095u) + 1u]++;
-                        for (uint32_t k2 = 0; k2 < 4096; k2++) bins[k2 + 1] += bins[k2];
-                        for (uint32_t i = 0; i < n; i++) ord[bins[key[i] & 4095u]++] = i;
-                    }
+                    ord.resize(n);
+                    for (uint32_t i = 0; i < n; i++) ord[i] = ((uint64_t)P.share_at[p0 + i] << 32) | i;
+                    std::sort(ord.begin(), ord.end());
                     tmp.assign(wd + p0, wd + p1);
                     uint32_t cur[8], end[8];
                     for (uint32_t x = 0; x < 8; x++) { cur[x] = (uint32_t)((uint64_t)n * x / 8); end[x] = (uint32_t)((uint64_t)n * (x + 1) / 8); }
                     for (uint32_t p = 0; p < n; p++) {
                         uint32_t x = (p0 + p) & 7u;
                         for (uint32_t tr = 0; tr < 8 && cur[x] >= end[x]; tr++) x = (x + 1) & 7u;   // a part one item short of its slots
-                        wd[p0 + p] = tmp[ord[cur[x]++]];
+                        wd[p0 + p] = tmp[(uint32_t)ord[cur[x]++]];
                     }
                 }
             });
@@ -1635,7 +1761,9 @@ extern "C" int ns_batch_run(ns_batch* b, int run_flags) {
         }
 #undef NS_U
 #undef NS_U2
-    } else if (b->n_witems) {
+    }
+#ifdef NS_VARIANTS
+    else if (b->n_witems) {
         const VariantDesc wv = kVariants[b->variant];
 #define NS_D(HH, FF) launch_dscore<HH, FF>(and_mode, b->n_witems, st, b->d_witems, b->d_terms, b->d_segs, sh, sn, sf, b->K)
         if (wv.d == 1) {
@@ -1654,12 +1782,16 @@ extern "C" int ns_batch_run(ns_batch* b, int run_flags) {
         }
 #undef NS_D
     }
-    if (b->n_items) {
+#endif
+    if (b->n_items) {   // term groups of more than 64 terms (and, in the variants build, every group of variants 1-4): the workgroup-tile kernel
+#ifdef NS_VARIANTS
         const VariantDesc vd = kVariants[b->variant];
         if (vd.nt == 1024) launch_score<1024, 12, 4>(and_mode, b->n_items, st, b->d_items, b->d_terms, b->d_segs, b->d_bounds, sh, sn, sf, b->K);
         else if (vd.nt == 256) launch_score<256, 16, 4>(and_mode, b->n_items, st, b->d_items, b->d_terms, b->d_segs, b->d_bounds, sh, sn, sf, b->K);
         else if (vd.spt == 16) launch_score<512, 16, 8>(and_mode, b->n_items, st, b->d_items, b->d_terms, b->d_segs, b->d_bounds, sh, sn, sf, b->K);
-        else launch_score<512, 12, 4>(and_mode, b->n_items, st, b->d_items, b->d_terms, b->d_segs, b->d_bounds, sh, sn, sf, b->K);
+        else
+#endif
+        launch_score<512, 12, 4>(and_mode, b->n_items, st, b->d_items, b->d_terms, b->d_segs, b->d_bounds, sh, sn, sf, b->K);
     }
     if (timed) HIPCHK(ctx, hipEventRecord(ev[2], st));
     if (!b->direct && b->Q > b->n_wide_q)
@@ -1817,7 +1949,7 @@ extern "C" int ns_batch_get_info(ns_batch* b, ns_batch_info* info) {
     info->n_term_refs = b->n_terms;
     info->tile_docs = b->tile_docs;
     info->k = b->K;
-    info->flags = b->flags | (b->imp ? NS_INFO_IMPACTS : 0u) | (b->pk ? NS_INFO_PACKED : 0u);
+    info->flags = b->flags | (b->imp ? NS_INFO_IMPACTS : 0u) | (b->pk ? NS_INFO_PACKED : 0u) | (b->pruned ? NS_INFO_PRUNED : 0u);
     info->last_score_kernel_ms = b->last_score_ms;
     info->last_total_ms = b->last_total_ms;
     info->timed_runs = b->timed_runs;

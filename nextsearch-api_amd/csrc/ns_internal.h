@@ -29,6 +29,8 @@ static constexpr uint32_t kPkStrideDwords = 512;   // 2 KB
 static constexpr uint32_t kPkTf = 0, kPkNormA = 64, kPkNormB = 128, kPkDoc = 192;
 // Skip tables: one entry per kSkipDocs docs == the doc-tile body's tile (k_uscore: 2 * HK slots).
 static constexpr uint32_t kSkipDocs = 1024;
+// Block maxima: one fp32 per kBmxBlock postings of a registered list.
+static constexpr uint32_t kBmxBlock = 256;
 
 struct DevSeg {
     const uint2* postings;   // {docId, tf} pairs, all inverted files of the segment back to back
@@ -45,6 +47,10 @@ struct DevSeg {
     // (into `postings`) of its first posting with docId >= i * kSkipDocs, i = 0 .. ceil(n_docs / kSkipDocs); one more entry
     // (= the list's end) so that the entry after next can always be read.  nullptr if never built
     const uint32_t* skips;
+    // optional block maxima (ns_segment_build_blockmax; SURVEY §8 f2, block-max scores): for a registered list, entry i = the
+    // largest BM25 term score — (idf * (tf * 2.2f)) / (tf + norm), src/api_engine.cpp:477-479, with the list's idf — among
+    // the postings [256 i, 256 i + 256) of the LIST (block i starts at the list's first posting + 256 i).  nullptr if never built
+    const float* blockmax;
     uint64_t     n_postings;
     uint32_t     n_docs;
     uint32_t     n_tiles;    // ceil(n_docs / tile_docs)
@@ -58,7 +64,7 @@ struct DevTerm {
     float    weight;     // qweight
     uint32_t seg;
     uint32_t skip;       // 0: no skip table; else 1 + index of the list's first entry in DevSeg::skips
-    uint32_t pad1;
+    uint32_t bmx;        // 0: no block maxima (or pruning off); else 1 + index of the list's first entry in DevSeg::blockmax
 };
 
 // Work item == one workgroup of k_score: one (query, segment) term group over a range of doc tiles.
@@ -92,6 +98,9 @@ struct DevWItem {
                            //        and the terms with DevTerm::skip != 0 take their postings of a tile from the skip table
                            // bit 6: driver-stream bodies: doc_lo (and doc_hi, unless it is n_docs) are multiples of kSkipDocs, and the
                            //        terms with DevTerm::skip != 0 take the range's ends in their lists from the skip table
+                           // bit 7: PRUNED single-term item (ns_ctx_use_pruning): the group's one list has block maxima (DevTerm::bmx);
+                           //        blocks whose best possible score cannot enter the item's top-K are not read; `found` is the
+                           //        number of the list's postings in the doc range (one list: every posting is a doc of its own)
 };
 
 // Term group == the (query, segment) unit the boundary prepass works on.

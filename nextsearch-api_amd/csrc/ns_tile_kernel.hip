@@ -19,6 +19,7 @@
 #include "ns_internal.h"
 #include "ns_wave_kernel.hip"
 #include "ns_driver_kernel.hip"
+#include "ns_prune_kernel.hip"
 
 namespace ns {
 
@@ -454,8 +455,11 @@ __global__ void __launch_bounds__(64 * kUscoreWavesPerBlock) __attribute__((amdg
     DevWItem it = items[item_idx];
     const bool tiles = (it.whole & 2u) != 0;
     const bool thin = (it.whole & 4u) != 0;   // the non-driver lists are thin: smallest foreign budget
+    const bool pruned = (it.whole & 128u) != 0;   // single-term item with block maxima (ns_ctx_use_pruning)
     it.whole &= 121u;   // bit 0: whole segment, bit 3: short division, bit 4: signed inputs, bits 5 / 6: skip grid (doc tiles / range ends)
-    if (thin)
+    if (pruned)
+        pscore_body<AND, CB>(it, terms, segs, s_cand[wave], out_hits, out_nhits, out_found, K, lane);
+    else if (thin)
         dscore_body<HK / 2, 64, AND, CB, IMP, PK>(it, terms, segs, s_tbl[wave], s_vals[wave], s_mcnt[wave], s_cand[wave],
                                  s_tab[wave], s_aux[wave], out_hits, out_nhits, out_found, K, lane);
     else if (tiles)

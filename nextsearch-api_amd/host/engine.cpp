@@ -22,9 +22,14 @@ float bm25_idf(uint32_t N, uint32_t df) {
 
 Engine::Engine(int device) : device_(device) {}
 
+Engine::Engine(const std::vector<int>& devices) : device_(devices.empty() ? 0 : devices[0]) {
+    for (size_t i = 1; i < devices.size(); i++) { Replica r; r.device = devices[i]; replicas_.push_back(r); }
+}
+
 Engine::~Engine() {
     release_device_segments();
     if (ctx_) ns_ctx_destroy(ctx_);
+    for (auto& r : replicas_) if (r.ctx) ns_ctx_destroy(r.ctx);   // frees the segments it holds
 }
 
 void Engine::release_device_segments() {
@@ -132,6 +137,7 @@ bool Engine::reload() {
 
     ns_ctx* fresh_ctx = nullptr;
     std::vector<ns_seg*> fresh_segs;
+    std::vector<Replica> fresh_replicas;
     if (device_ >= 0) {
         int rc = ns_ctx_create(device_, &fresh_ctx);
         if (rc != NS_OK) { err_ = std::string("ns_ctx_create: ") + ns_last_error(nullptr); return false; }
@@ -143,8 +149,19 @@ bool Engine::reload() {
             rc = ns_sem_upload(fresh_ctx, fresh_sem.vecs.data(), (uint32_t)fresh_sem.terms.size(), (uint32_t)fresh_sem.dim, &fresh_sem.dev);
             if (rc != NS_OK) { err_ = std::string("ns_sem_upload: ") + ns_last_error(fresh_ctx); ok = false; }
         }
+        // the replicas of a multi-device engine: the same upload into a fresh context on each further device
+        for (size_t r = 0; r < replicas_.size() && ok; r++) {
+            Replica fr;
+            fr.device = replicas_[r].device;
+            rc = ns_ctx_create(fr.device, &fr.ctx);
+            if (rc != NS_OK) { err_ = std::string("ns_ctx_create (device ") + std::to_string(fr.device) + "): " + ns_last_error(nullptr); ok = false; break; }
+            fr.segs.assign(loaded.size(), nullptr);
+            for (size_t i = 0; i < loaded.size() && ok; i++) ok = upload_segment(fr.ctx, (uint32_t)i, loaded[i], &fr.segs[i], err_);
+            fresh_replicas.push_back(fr);
+        }
         if (!ok) {   // the engine keeps serving the previous index
             ns_ctx_destroy(fresh_ctx);   // frees the segments it holds
+            for (auto& fr : fresh_replicas) if (fr.ctx) ns_ctx_destroy(fr.ctx);
             return false;
         }
     }
@@ -153,6 +170,10 @@ bool Engine::reload() {
     if (ctx_) ns_ctx_destroy(ctx_);
     ctx_ = fresh_ctx;
     dev_segs_ = std::move(fresh_segs);
+    if (device_ >= 0) {
+        for (auto& r : replicas_) if (r.ctx) ns_ctx_destroy(r.ctx);
+        replicas_ = std::move(fresh_replicas);
+    }
     seg_names = std::move(names);
     segments = std::move(loaded);
     meta = std::move(fresh_meta);
@@ -211,6 +232,10 @@ bool Engine::build_impacts() {
         }
         int rc = ns_segment_build_impacts(ctx_, dev_segs_[sid], off.data(), cnt.data(), idf.data(), (uint32_t)off.size());
         if (rc != NS_OK) { err_ = std::string("ns_segment_build_impacts: ") + ns_last_error(ctx_); return false; }
+        for (auto& r : replicas_) {
+            rc = ns_segment_build_impacts(r.ctx, r.segs[sid], off.data(), cnt.data(), idf.data(), (uint32_t)off.size());
+            if (rc != NS_OK) { err_ = std::string("ns_segment_build_impacts: ") + ns_last_error(r.ctx); return false; }
+        }
     }
     return true;
 }
@@ -222,15 +247,66 @@ bool Engine::build_packed() {
     for (size_t sid = 0; sid < dev_segs_.size(); sid++) {
         int rc = ns_segment_build_packed(ctx_, dev_segs_[sid]);
         if (rc != NS_OK) { err_ = std::string("ns_segment_build_packed: ") + ns_last_error(ctx_); return false; }
+        for (auto& r : replicas_) {
+            rc = ns_segment_build_packed(r.ctx, r.segs[sid]);
+            if (rc != NS_OK) { err_ = std::string("ns_segment_build_packed: ") + ns_last_error(r.ctx); return false; }
+        }
     }
     return true;
 }
 
-void Engine::use_packed(int mode) { std::lock_guard<std::recursive_mutex> lock(mtx_); if (ctx_) ns_ctx_use_packed(ctx_, mode); }
+// Optional: block maxima of every list long enough for pruning to pay (ns_segment_build_blockmax).
+bool Engine::build_blockmax() {
+    std::lock_guard<std::recursive_mutex> lock(mtx_);
+    if (!ctx_) { err_ = "no device context"; return false; }
+    for (size_t sid = 0; sid < segments.size(); sid++) {
+        const auto& seg = segments[sid];
+        std::vector<uint64_t> off;
+        std::vector<uint32_t> cnt;
+        std::vector<float> idf;
+        for (const auto& kv : seg.lex) {
+            const nsx::LexEntry& e = kv.second;
+            if (e.df == 0 || e.count < 512) continue;
+            if (seg.use_barrels && e.barrelId >= seg.barrel_base.size()) continue;
+            const uint64_t bo = seg.list_byte_offset(e);
+            if (bo % 8 != 0 || bo / 8 + e.count > seg.postings_bytes / 8) continue;   // a damaged record: never scored either
+            off.push_back(bo);
+            cnt.push_back(e.count);
+            idf.push_back(bm25_idf(seg.N, e.df));   // the idf build_refs hands to the device for this list
+        }
+        int rc = ns_segment_build_blockmax(ctx_, dev_segs_[sid], off.data(), cnt.data(), idf.data(), (uint32_t)off.size());
+        if (rc != NS_OK) { err_ = std::string("ns_segment_build_blockmax: ") + ns_last_error(ctx_); return false; }
+        for (auto& r : replicas_) {
+            rc = ns_segment_build_blockmax(r.ctx, r.segs[sid], off.data(), cnt.data(), idf.data(), (uint32_t)off.size());
+            if (rc != NS_OK) { err_ = std::string("ns_segment_build_blockmax: ") + ns_last_error(r.ctx); return false; }
+        }
+    }
+    return true;
+}
 
-void Engine::use_skips(bool on) { std::lock_guard<std::recursive_mutex> lock(mtx_); if (ctx_) ns_ctx_use_skips(ctx_, on ? 1 : 0); }
+void Engine::use_pruning(bool on) {
+    std::lock_guard<std::recursive_mutex> lock(mtx_);
+    if (ctx_) ns_ctx_use_pruning(ctx_, on ? 1 : 0);
+    for (auto& r : replicas_) ns_ctx_use_pruning(r.ctx, on ? 1 : 0);
+}
 
-void Engine::use_impacts(bool on) { std::lock_guard<std::recursive_mutex> lock(mtx_); if (ctx_) ns_ctx_use_impacts(ctx_, on ? 1 : 0); }
+void Engine::use_packed(int mode) {
+    std::lock_guard<std::recursive_mutex> lock(mtx_);
+    if (ctx_) ns_ctx_use_packed(ctx_, mode);
+    for (auto& r : replicas_) ns_ctx_use_packed(r.ctx, mode);
+}
+
+void Engine::use_skips(bool on) {
+    std::lock_guard<std::recursive_mutex> lock(mtx_);
+    if (ctx_) ns_ctx_use_skips(ctx_, on ? 1 : 0);
+    for (auto& r : replicas_) ns_ctx_use_skips(r.ctx, on ? 1 : 0);
+}
+
+void Engine::use_impacts(bool on) {
+    std::lock_guard<std::recursive_mutex> lock(mtx_);
+    if (ctx_) ns_ctx_use_impacts(ctx_, on ? 1 : 0);
+    for (auto& r : replicas_) ns_ctx_use_impacts(r.ctx, on ? 1 : 0);
+}
 
 // Query preparation (tokenise, stop-words, lexicon probes, idf: src/api_engine.cpp:388-397,:454-461) for
 // queries [q0, q1) with GIVEN weighted terms (semantic expansion): `refs` receives the term refs of those queries,
@@ -392,31 +468,16 @@ bool Engine::search_batch(const std::vector<std::string>& queries, int k, uint32
 // one — the only host work the device does not hide — is a small part of the call.
 static constexpr size_t kSubBatch = 4096;
 
-bool Engine::search_batch_flat(const QueryView* queries, size_t Q, int k, uint32_t flags, ns_hit* hits, uint32_t* nhits,
-                               uint64_t* found, uint8_t* usable) {
-    std::lock_guard<std::recursive_mutex> lock(mtx_);
-    if (!ctx_) { err_ = "no device context: this engine has no CPU scoring path"; return false; }
-    if (Q && (!queries || !hits || !nhits || !found || !usable)) { err_ = "search_batch_flat: null argument"; return false; }
-    const int K = std::max(1, std::min(k, 100));   // src/api_engine.cpp:377
+// One contiguous range [q0, q1) of a batch on one context.  Two or more sub-batches: prepare(i + 1) on the host || kernels(i)
+// on the device || results(i - 1) on their way back.  pooled_prep: query preparation on the engine's host threads (the one
+// range of a single-device engine); otherwise on the calling thread (a multi-device engine runs one such call per device).
+bool Engine::run_range(ns_ctx* ctx, const QueryView* queries, size_t q0, size_t q1, int K, uint32_t flags, ns_hit* hits, uint32_t* nhits,
+                       uint64_t* found, uint8_t* usable, bool pooled_prep, std::string& err) {
+    const size_t Q = q1 - q0;
     if (Q == 0) return true;
-    if (sem.enabled) {
-        // semantic expansion runs the whole batch through two device calls first (src/api_engine.cpp:409-417): not pipelined
-        std::vector<std::string> qs(Q);
-        for (size_t q = 0; q < Q; q++) qs[q].assign(queries[q].p, queries[q].n);
-        std::vector<ns_query_desc> qd;
-        std::vector<ns_term_ref> refs;
-        std::vector<uint8_t> us;
-        build_refs(qs, qd, refs, us);
-        if (refs_failed_) return false;
-        std::memcpy(usable, us.data(), Q);
-        int rc = ns_search_batch(ctx_, qd.data(), refs.data(), (uint32_t)Q, (uint32_t)K, hits, nhits, found, flags);
-        if (rc != NS_OK) { err_ = std::string("ns_search_batch: ") + ns_last_error(ctx_); return false; }
-        return true;
-    }
-    // two or more sub-batches: prepare(i + 1) on the host || kernels(i) on the device || results(i - 1) on their way back
     const size_t n_sub = Q >= 2 * kSubBatch ? (Q + kSubBatch - 1) / kSubBatch : 1;
     const bool piped = n_sub > 1;
-    if (piped) (void)ns_ctx_set_overlap(ctx_, 1);
+    if (piped) (void)ns_ctx_set_overlap(ctx, 1);
     struct InFlight { ns_batch* b = nullptr; size_t q0 = 0; };
     InFlight prev;
     bool ok = true;
@@ -424,22 +485,30 @@ bool Engine::search_batch_flat(const QueryView* queries, size_t Q, int k, uint32
         if (!f.b) return;
         if (ok) {
             const int rc = ns_batch_fetch(f.b, hits + f.q0 * (size_t)K, nhits + f.q0, found + f.q0);
-            if (rc != NS_OK) { err_ = std::string("ns_batch_fetch: ") + ns_last_error(ctx_); ok = false; }
+            if (rc != NS_OK) { err = std::string("ns_batch_fetch: ") + ns_last_error(ctx); ok = false; }
         }
         ns_batch_destroy(f.b);
         f.b = nullptr;
     };
-    std::vector<ns_query_desc>& qd = flat_qd_;
-    std::vector<ns_term_ref>& refs = flat_refs_;
+    std::vector<ns_query_desc> own_qd;
+    std::vector<ns_term_ref> own_refs;
+    PrepScratch own_sc;
+    std::vector<ns_query_desc>& qd = pooled_prep ? flat_qd_ : own_qd;
+    std::vector<ns_term_ref>& refs = pooled_prep ? flat_refs_ : own_refs;
     for (size_t i = 0; i < n_sub && ok; i++) {
-        const size_t q0 = Q * i / n_sub, q1 = Q * (i + 1) / n_sub;
-        build_refs_parallel(queries, q0, q1, qd, refs, usable + q0);
+        const size_t a = q0 + Q * i / n_sub, b = q0 + Q * (i + 1) / n_sub;
+        if (pooled_prep) build_refs_parallel(queries, a, b, qd, refs, usable + a);
+        else {
+            qd.resize(b - a);
+            refs.clear();
+            build_refs_views(queries, a, b, qd.data(), refs, usable + a, own_sc.text, own_sc.gids);
+        }
         InFlight cur;
-        cur.q0 = q0;
-        int rc = ns_batch_prepare(ctx_, qd.data(), refs.data(), (uint32_t)(q1 - q0), (uint32_t)K, flags, &cur.b);
+        cur.q0 = a;
+        int rc = ns_batch_prepare(ctx, qd.data(), refs.data(), (uint32_t)(b - a), (uint32_t)K, flags, &cur.b);
         if (rc == NS_OK) rc = ns_batch_run(cur.b, NS_RUN_FETCH);
         if (rc != NS_OK) {
-            err_ = std::string("ns_batch_prepare/run: ") + ns_last_error(ctx_);
+            err = std::string("ns_batch_prepare/run: ") + ns_last_error(ctx);
             ok = false;
             if (cur.b) ns_batch_destroy(cur.b);
             break;
@@ -448,8 +517,69 @@ bool Engine::search_batch_flat(const QueryView* queries, size_t Q, int k, uint32
         prev = cur;
     }
     retire(prev);
-    if (piped) (void)ns_ctx_set_overlap(ctx_, 0);
+    if (piped) (void)ns_ctx_set_overlap(ctx, 0);
     return ok;
+}
+
+bool Engine::search_batch_flat(const QueryView* queries, size_t Q, int k, uint32_t flags, ns_hit* hits, uint32_t* nhits,
+                               uint64_t* found, uint8_t* usable) {
+    std::lock_guard<std::recursive_mutex> lock(mtx_);
+    if (!ctx_) { err_ = "no device context: this engine has no CPU scoring path"; return false; }
+    if (Q && (!queries || !hits || !nhits || !found || !usable)) { err_ = "search_batch_flat: null argument"; return false; }
+    const int K = std::max(1, std::min(k, 100));   // src/api_engine.cpp:377
+    if (Q == 0) return true;
+    const size_t n_dev = num_devices();
+    if (sem.enabled) {
+        // semantic expansion runs the whole batch through two device calls on the primary context first
+        // (src/api_engine.cpp:409-417); the scoring of the expanded terms is then sharded like any other batch
+        std::vector<std::string> qs(Q);
+        for (size_t q = 0; q < Q; q++) qs[q].assign(queries[q].p, queries[q].n);
+        std::vector<ns_query_desc> qd;
+        std::vector<ns_term_ref> refs;
+        std::vector<uint8_t> us;
+        build_refs(qs, qd, refs, us);
+        if (refs_failed_) return false;
+        std::memcpy(usable, us.data(), Q);
+        std::vector<std::string> errs(n_dev);
+        std::vector<int> rcs(n_dev, NS_OK);
+        auto shard = [&](size_t d) {
+            const auto [a, b] = n_dev > 1 ? shard_bounds(Q, d, n_dev) : std::pair<size_t, size_t>{0, Q};
+            if (a >= b) return;
+            ns_ctx* c = d == 0 ? ctx_ : replicas_[d - 1].ctx;
+            // the shard's descriptors: term_begin stays an index into the one refs array
+            rcs[d] = ns_search_batch(c, qd.data() + a, refs.data(), (uint32_t)(b - a), (uint32_t)K, hits + a * (size_t)K, nhits + a, found + a, flags);
+            if (rcs[d] != NS_OK) errs[d] = std::string("ns_search_batch: ") + ns_last_error(c);
+        };
+        if (n_dev > 1 && Q >= 2 * n_dev) {
+            std::vector<std::thread> th;
+            for (size_t d = 1; d < n_dev; d++) th.emplace_back(shard, d);
+            shard(0);
+            for (auto& t : th) t.join();
+        } else {
+            const size_t keep = n_dev; (void)keep;
+            rcs[0] = ns_search_batch(ctx_, qd.data(), refs.data(), (uint32_t)Q, (uint32_t)K, hits, nhits, found, flags);
+            if (rcs[0] != NS_OK) errs[0] = std::string("ns_search_batch: ") + ns_last_error(ctx_);
+        }
+        for (size_t d = 0; d < n_dev; d++) if (rcs[d] != NS_OK) { err_ = errs[d]; return false; }
+        return true;
+    }
+    if (n_dev > 1 && Q >= 2 * n_dev) {
+        // one host thread + context per device, contiguous shards of ceil(Q / N) queries
+        std::vector<std::string> errs(n_dev);
+        std::vector<char> oks(n_dev, 1);
+        auto shard = [&](size_t d) {
+            const auto [a, b] = shard_bounds(Q, d, n_dev);
+            ns_ctx* c = d == 0 ? ctx_ : replicas_[d - 1].ctx;
+            oks[d] = run_range(c, queries, a, b, K, flags, hits, nhits, found, usable, /*pooled_prep*/ false, errs[d]) ? 1 : 0;
+        };
+        std::vector<std::thread> th;
+        for (size_t d = 1; d < n_dev; d++) th.emplace_back(shard, d);
+        shard(0);
+        for (auto& t : th) t.join();
+        for (size_t d = 0; d < n_dev; d++) if (!oks[d]) { err_ = errs[d]; return false; }
+        return true;
+    }
+    return run_range(ctx_, queries, 0, Q, K, flags, hits, nhits, found, usable, /*pooled_prep*/ true, err_);
 }
 
 bool Engine::search_batch_locked(const std::vector<std::string>& queries, int k, uint32_t flags, std::vector<SearchResult>& out) {

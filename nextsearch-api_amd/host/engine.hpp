@@ -19,6 +19,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/nextsearch_hip.h"
@@ -61,6 +62,21 @@ public:
 
     // device < 0: host-only (index + query preparation; every search call fails loudly)
     explicit Engine(int device = 0);
+    // SURVEY.md 8(e), "one host thread + ns_ctx per GPU": the index is REPLICATED on every listed device (reload() uploads
+    // it to each), and search_batch_flat / search_batch cut a batch into contiguous shards of ceil(Q / N) queries, one per
+    // device, each driven by its own host thread through its own context; the shards' results land in the caller's one
+    // set of host arrays (plain D2H per device: in one process no collective is needed — bench.py's multi-PROCESS form
+    // keeps the RCCL all-gather).  Queries are independent (the reference serialises them behind one mutex,
+    // src/api_engine.cpp:372), so the cut changes no result.  The same device may be listed twice (two contexts on one
+    // GPU: what the one-GPU test box exercises).  devices[0] is the primary context: single searches, semantic
+    // expansion's similarity search and ctx() use it.
+    explicit Engine(const std::vector<int>& devices);
+    size_t num_devices() const { return 1 + replicas_.size(); }
+    // [begin, end) of shard r of n over Q queries: contiguous, ceil(Q / n) each, the last ones short or empty
+    static std::pair<size_t, size_t> shard_bounds(size_t Q, size_t r, size_t n) {
+        const size_t per = n ? (Q + n - 1) / n : Q;
+        return {std::min(Q, r * per), std::min(Q, (r + 1) * per)};
+    }
     ~Engine();
     Engine(const Engine&) = delete;
     Engine& operator=(const Engine&) = delete;
@@ -76,6 +92,11 @@ public:
     // built on the device next to the raw stream (ns_segment_build_packed); the driver streams then read 4-7 B per posting
     // instead of 12.  Same results.
     bool build_packed();
+    // Optional (block-max scores): per 256 postings of every list of >= 512 postings the largest term score,
+    // built on the device (ns_segment_build_blockmax).  use_pruning(true): single-term queries then skip, unread, the blocks
+    // that cannot enter their top-K; `found` stays exact (it is the list's posting count).  Same results; off by default.
+    bool build_blockmax();
+    void use_pruning(bool on);
     void use_packed(int mode);   // 0 off, 1 packed docIds + tf with the fp32 norm stream (default), 2 norms through the 16-bit index
     std::string search(const std::string& query, int k);        // include/api_engine.hpp:66 (JSON text, dump(2) layout)
     // Search-result cache around search() (src/api_engine.cpp:190-250,:380-385,:539): key "query|K", at most 2600
@@ -148,6 +169,12 @@ private:
     int device_;
     ns_ctx* ctx_ = nullptr;
     std::vector<ns_seg*> dev_segs_;
+    // further devices holding a replica of the index (multi-device engine): context + segments each
+    struct Replica { int device = 0; ns_ctx* ctx = nullptr; std::vector<ns_seg*> segs; };
+    std::vector<Replica> replicas_;
+    // one contiguous range of a batch on one context: sub-batches pipelined (prepare(i+1) || kernels(i) || results(i-1))
+    bool run_range(ns_ctx* ctx, const QueryView* queries, size_t q0, size_t q1, int K, uint32_t flags, ns_hit* hits, uint32_t* nhits,
+                   uint64_t* found, uint8_t* usable, bool pooled_prep, std::string& err);
     mutable std::string err_;
 };
 

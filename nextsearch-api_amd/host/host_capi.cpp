@@ -16,6 +16,7 @@ struct nsh_engine {
     nextsearch::Engine eng;
     std::string err;
     explicit nsh_engine(int device) : eng(device) {}
+    explicit nsh_engine(const std::vector<int>& devices) : eng(devices) {}
 };
 
 static void nsh_note(nsh_engine* e, const char* where, const char* what) {
@@ -60,6 +61,23 @@ extern "C" int nsh_engine_open(const char* index_dir, int device, nsh_engine** o
     if (!e->eng.reload()) { e->err = e->eng.last_error(); return -1; }
     return 0;
 } NSH_CATCH(out ? *out : nullptr, "nsh_engine_open", -1)
+}
+
+extern "C" int nsh_engine_open_multi(const char* index_dir, const int* devices, uint32_t n_devices, nsh_engine** out) { try {
+    if (!out || !devices || n_devices == 0) return -1;
+    nsh_engine* e = new nsh_engine(std::vector<int>(devices, devices + n_devices));
+    e->eng.index_dir = index_dir ? index_dir : "";
+    *out = e;
+    if (!e->eng.reload()) { e->err = e->eng.last_error(); return -1; }
+    return 0;
+} NSH_CATCH(out ? *out : nullptr, "nsh_engine_open_multi", -1)
+}
+extern "C" uint32_t nsh_engine_num_devices(nsh_engine* e) { try { return e ? (uint32_t)e->eng.num_devices() : 0; } NSH_CATCH(e, "nsh_engine_num_devices", 0)
+}
+extern "C" void nsh_shard_bounds(uint64_t n_queries, uint32_t r, uint32_t n, uint64_t* begin, uint64_t* end) {
+    const auto b = nextsearch::Engine::shard_bounds((size_t)n_queries, r, n);
+    if (begin) *begin = b.first;
+    if (end) *end = b.second;
 }
 
 extern "C" void nsh_engine_close(nsh_engine* e) { delete e; }
@@ -334,6 +352,14 @@ extern "C" int nsh_engine_build_packed(nsh_engine* e) { try {
 } NSH_CATCH(e, "nsh_engine_build_packed", -1)
 }
 extern "C" void nsh_engine_use_packed(nsh_engine* e, int on) { try { if (e) e->eng.use_packed(on); } NSH_CATCH_VOID(e, "nsh_engine_use_packed")
+}
+extern "C" int nsh_engine_build_blockmax(nsh_engine* e) { try {
+    if (!e) return -1;
+    if (!e->eng.build_blockmax()) { e->err = e->eng.last_error(); return -1; }
+    return 0;
+} NSH_CATCH(e, "nsh_engine_build_blockmax", -1)
+}
+extern "C" void nsh_engine_use_pruning(nsh_engine* e, int on) { try { if (e) e->eng.use_pruning(on != 0); } NSH_CATCH_VOID(e, "nsh_engine_use_pruning")
 }
 extern "C" void nsh_engine_use_skips(nsh_engine* e, int on) { try { if (e) e->eng.use_skips(on != 0);  } NSH_CATCH_VOID(e, "nsh_engine_use_skips")
 }

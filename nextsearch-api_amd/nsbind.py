@@ -11,7 +11,9 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB_PATH = os.path.join(HERE, "libnextsearch_hip.so")
+# NS_HIP_LIB: another build of the HIP library for THIS process (tests/variants: libnextsearch_hip_variants.so; A/B runs).
+# It is loaded first and globally, and carries the product library's SONAME, so the host library binds to it too.
+HIP_LIB_PATH = os.environ.get("NS_HIP_LIB") or os.path.join(HERE, "libnextsearch_hip.so")
 HOST_LIB_PATH = os.path.join(HERE, "libnextsearch_host.so")
 
 NS_OK = 0
@@ -19,6 +21,7 @@ NS_FLAG_OR = 0
 NS_FLAG_AND = 1
 NS_INFO_IMPACTS = 0x100
 NS_INFO_PACKED = 0x200
+NS_INFO_PRUNED = 0x400
 NS_MAX_K = 100
 
 
@@ -55,16 +58,16 @@ HIP_SYMBOLS = [
     "ns_ctx_create", "ns_ctx_destroy", "ns_ctx_set_stream", "ns_last_error", "ns_device_name",
     "ns_segment_upload", "ns_segment_release", "ns_segment_upload_begin", "ns_segment_upload_append", "ns_segment_upload_end", "ns_search_batch", "ns_batch_prepare",
     "ns_batch_bind_outputs", "ns_batch_run", "ns_batch_stream", "ns_batch_gap_ms", "ns_batch_sync", "ns_batch_fetch", "ns_batch_get_info",
-    "ns_batch_destroy", "ns_set_tuning", "ns_segment_build_impacts", "ns_ctx_use_impacts", "ns_ctx_set_host_threads", "ns_ctx_set_overlap", "ns_segment_build_packed", "ns_ctx_use_packed", "ns_segment_build_skips", "ns_ctx_use_skips",
+    "ns_batch_destroy", "ns_set_tuning", "ns_segment_build_impacts", "ns_ctx_use_impacts", "ns_ctx_set_host_threads", "ns_ctx_set_overlap", "ns_segment_build_packed", "ns_ctx_use_packed", "ns_segment_build_skips", "ns_ctx_use_skips", "ns_segment_build_blockmax", "ns_ctx_use_pruning",
     "ns_invert_forward", "ns_segment_upload_inverted", "ns_merge_rank_rows", "ns_sem_upload", "ns_sem_release", "ns_sem_topk",
 ]
 HOST_SYMBOLS = [
-    "nsh_gen_index", "nsh_engine_open", "nsh_engine_close", "nsh_engine_reload", "nsh_engine_error", "nsh_engine_ctx",
+    "nsh_gen_index", "nsh_engine_open", "nsh_engine_open_multi", "nsh_engine_num_devices", "nsh_shard_bounds", "nsh_engine_close", "nsh_engine_reload", "nsh_engine_error", "nsh_engine_ctx",
     "nsh_engine_num_segments", "nsh_engine_segment_name", "nsh_engine_segment_info",
     "nsh_engine_segment_doc_len", "nsh_engine_segment_postings", "nsh_engine_lookup", "nsh_bm25_idf",
     "nsh_base_terms", "nsh_engine_build_refs", "nsh_engine_search_json", "nsh_free",
     "nsh_engine_search_batch", "nsh_engine_prepare", "nsh_engine_doc_metadata", "nsh_engine_hits_to_json", "nsh_engine_search_batch_json",
-    "nsh_engine_build_impacts", "nsh_engine_use_impacts", "nsh_engine_build_packed", "nsh_engine_use_packed", "nsh_engine_use_skips", "nsh_invert_segment", "nsh_invert_error",
+    "nsh_engine_build_impacts", "nsh_engine_use_impacts", "nsh_engine_build_packed", "nsh_engine_use_packed", "nsh_engine_build_blockmax", "nsh_engine_use_pruning", "nsh_engine_use_skips", "nsh_invert_segment", "nsh_invert_error",
     "nsh_engine_semantic_info", "nsh_engine_expand", "nsh_engine_semantic_row", "nsh_engine_set_cache", "nsh_engine_cache_size",
 ]
 
@@ -101,6 +104,8 @@ def hip_lib():
         L.ns_ctx_set_overlap.argtypes = [vp, i32]
         L.ns_segment_build_packed.argtypes = [vp, vp]
         L.ns_ctx_use_packed.argtypes = [vp, i32]
+        L.ns_segment_build_blockmax.argtypes = [vp, vp, vp, vp, vp, u32]
+        L.ns_ctx_use_pruning.argtypes = [vp, i32]
         L.ns_sem_upload.argtypes = [vp, vp, u32, u32, C.POINTER(vp)]
         L.ns_sem_release.argtypes = [vp, vp]
         L.ns_sem_topk.argtypes = [vp, vp, vp, u32, u32, C.c_float, vp, vp, vp, vp, vp, vp]
@@ -134,6 +139,11 @@ def host_lib():
         vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
         L.nsh_gen_index.argtypes = [C.c_char_p, u32, u32, u32, u64, i32, C.POINTER(u64)]
         L.nsh_engine_open.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
+        L.nsh_engine_open_multi.argtypes = [C.c_char_p, C.POINTER(i32), u32, C.POINTER(vp)]
+        L.nsh_engine_num_devices.argtypes = [vp]
+        L.nsh_engine_num_devices.restype = u32
+        L.nsh_shard_bounds.argtypes = [C.c_uint64, u32, u32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.nsh_shard_bounds.restype = None
         L.nsh_engine_close.argtypes = [vp]
         L.nsh_engine_close.restype = None
         L.nsh_engine_reload.argtypes = [vp]
@@ -183,6 +193,9 @@ def host_lib():
         L.nsh_engine_build_packed.argtypes = [vp]
         L.nsh_engine_use_packed.argtypes = [vp, i32]
         L.nsh_engine_use_packed.restype = None
+        L.nsh_engine_build_blockmax.argtypes = [vp]
+        L.nsh_engine_use_pruning.argtypes = [vp, i32]
+        L.nsh_engine_use_pruning.restype = None
         _host = L
     return _host
 
@@ -268,9 +281,15 @@ class Engine:
     """Python view of the host facade (mirror of cord19::Engine: reload at open, search, search_batch)."""
 
     def __init__(self, index_dir, device=0):
+        """device: one device id (< 0: host-only), or a list of device ids: the multi-device engine (index replicated,
+        batches cut into contiguous shards, one host thread + context per device)."""
         self._L = host_lib()
         h = C.c_void_p()
-        rc = self._L.nsh_engine_open(index_dir.encode(), device, C.byref(h))
+        if isinstance(device, (list, tuple)):
+            arr = (C.c_int32 * len(device))(*device)
+            rc = self._L.nsh_engine_open_multi(index_dir.encode(), arr, len(device), C.byref(h))
+        else:
+            rc = self._L.nsh_engine_open(index_dir.encode(), device, C.byref(h))
         self.h = h
         if rc != 0:
             msg = self._L.nsh_engine_error(h).decode()
@@ -289,6 +308,10 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+    @property
+    def num_devices(self):
+        return self._L.nsh_engine_num_devices(self.h)
 
     def reload(self):
         """Engine::reload() on the same directory; on failure the engine keeps what it had."""
@@ -441,6 +464,15 @@ class Engine:
         """Precompute every list's per-posting term scores on the device (optional second posting stream)."""
         if self._L.nsh_engine_build_impacts(self.h) != 0:
             raise RuntimeError(f"build_impacts failed: {self.error()}")
+
+    def build_blockmax(self):
+        """Block maxima for every list of >= 512 postings (ns_segment_build_blockmax); see use_pruning."""
+        if self._L.nsh_engine_build_blockmax(self.h) != 0:
+            raise RuntimeError(f"build_blockmax failed: {self.error()}")
+
+    def use_pruning(self, on):
+        """Single-term queries skip the blocks that cannot enter their top-K (found stays exact); off by default."""
+        self._L.nsh_engine_use_pruning(self.h, 1 if on else 0)
 
     def build_packed(self):
         """Build every segment's compressed, blocked posting stream on the device (optional)."""

@@ -12,12 +12,24 @@ sys.path.insert(0, PKG)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+# The forced kernel variants (ns_set_tuning variant != 0) live in libnextsearch_hip_variants.so, not in the product library.
+# A process that set NS_HIP_LIB to that build runs the variant cases; every other process skips them, and ONE test of the
+# main suite (test_gpu_parity.py::test_forced_kernel_variants_in_the_variants_build) runs them in such a process.
+VARIANTS_LIB = os.path.join(PKG, "libnextsearch_hip_variants.so")
+VARIANTS_BUILD = "variants" in os.path.basename(os.environ.get("NS_HIP_LIB", ""))
+
+
+def need_variants(variant):
+    if variant != 0 and not VARIANTS_BUILD:
+        pytest.skip("forced kernel variants run in the variants build (see test_forced_kernel_variants_in_the_variants_build)")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
 def _ensure_built():
-    need = [os.path.join(PKG, "libnextsearch_hip.so"), os.path.join(PKG, "libnextsearch_host.so")]
+    need = [os.path.join(PKG, "libnextsearch_hip.so"), os.path.join(PKG, "libnextsearch_host.so"), VARIANTS_LIB]
     if not all(os.path.exists(p) for p in need):
         subprocess.run(["make", "-s", "-C", PKG, "all"], check=True)
     if not os.path.exists(os.path.join(ROOT, "oracle", "libbm25_oracle.so")):

@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 import pytest
-from conftest import GOLDEN_NAMES
+from conftest import GOLDEN_NAMES, VARIANTS_BUILD, VARIANTS_LIB, need_variants
 
 import nsbind
 import orc
@@ -74,6 +74,7 @@ def test_gpu_equals_oracle_and_reference_golden(name, engines):
 @pytest.mark.parametrize("variant", [1, 2, 3, 4, 12, 13, 14, 15, 16, 17, 18, 19, 20])
 def test_kernel_variants_agree(variant, engines):
     """Wave-private kernel (5/6/7: 256/512/1024-entry tables) and workgroup-tile kernel (1..4)."""
+    need_variants(variant)
     g, eng, ora = engines("mid1")
     queries = g["queries"]
     eng.set_tuning(variant, 0, 0)
@@ -91,6 +92,7 @@ def test_kernel_variants_agree(variant, engines):
 def test_doc_range_splitting_is_invisible(variant, min_items, split, engines):
     """Queries are split into doc ranges (by posting budget, and to fill the chip for small batches)
     and re-joined on the device by k_merge; the result must not depend on the split."""
+    need_variants(variant)
     g, eng, ora = engines("mid1")
     queries = g["queries"][:20]
     eng.set_tuning(variant, min_items, split)
@@ -112,7 +114,30 @@ def test_retired_variants_are_rejected(engines):
     for v in (5, 6, 7, 8, 9, 10, 11, 21, 1000):
         with pytest.raises(RuntimeError, match="unknown kernel variant"):
             eng.set_tuning(v, 0, 0)
+    if not VARIANTS_BUILD:   # the product library holds variant 0 only; it says where the others are
+        for v in (1, 2, 3, 4, 12, 13, 14, 15, 16, 17, 18, 19, 20):
+            with pytest.raises(RuntimeError, match="variants build"):
+                eng.set_tuning(v, 0, 0)
     eng.set_tuning(0, 0, 0)
+
+
+def test_forced_kernel_variants_in_the_variants_build():
+    """The 13 forced kernel variants (each scoring body as a kernel of its own, other table and tile sizes) are test and
+    sweep infrastructure: libnextsearch_hip_variants.so (`make -C nextsearch-api_amd variants`) holds them, the product
+    library does not.  Their parity cases — every variant against the oracle, doc-range splitting, zero-tf / signed
+    inputs, equal scores — run here in ONE child process that loads that build (NS_HIP_LIB)."""
+    import subprocess
+    import sys
+    if VARIANTS_BUILD:
+        pytest.skip("this IS the variants process")
+    assert os.path.exists(VARIANTS_LIB), "libnextsearch_hip_variants.so is missing: make -C nextsearch-api_amd variants"
+    env = dict(os.environ, NS_HIP_LIB=VARIANTS_LIB)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
+                        "-k", "kernel_variants_agree or doc_range_splitting or zero_tf_postings or equal_scores_in_doc_tiles or retired_variants"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], tail
 
 
 @pytest.mark.parametrize("variant,split", [(0, 0), (0, 300), (12, 0), (13, 200), (18, 0), (19, 0), (20, 300), (2, 0)])
@@ -122,6 +147,7 @@ def test_zero_tf_postings_and_signed_weights(variant, split):
     reference's `0.0f + x` turns into +0.0f.  Raw C-ABI, one segment with tf == 0 postings sprinkled into dense and
     sparse lists, positive and negative idfs / weights, every scoring body: found, order and score BITS against a
     numpy fp32 restatement that starts every doc at +0.0f."""
+    need_variants(variant)
     L = nsbind.hip_lib()
     ctx = C.c_void_p()
     assert L.ns_ctx_create(0, C.byref(ctx)) == 0
@@ -179,6 +205,7 @@ def test_equal_scores_in_doc_tiles_and_skip_tables(variant, split, skips):
     slots in and wherever the candidate buffer is shrunk (a shrink inside a tile leaves ties with the threshold that
     still win on docId).  Raw C-ABI; with skip tables (ns_segment_build_skips) for all lists (2), for some (1: the
     others keep their cursors inside the same grid tiles) or none (0), plus an unsorted list, which must get no table."""
+    need_variants(variant)
     L = nsbind.hip_lib()
     ctx = C.c_void_p()
     assert L.ns_ctx_create(0, C.byref(ctx)) == 0
@@ -284,6 +311,13 @@ def test_full_batches_equal_oracle_and_reference_digests(index_factory):
                 eng.use_packed(pk)
                 h2, n2, f2, _ = eng.search_batch(gen(Q), K, flags)
                 assert hits.tobytes() == h2.tobytes() and nhits.tobytes() == n2.tobytes() and found.tobytes() == f2.tobytes(), (cfg, "packed", pk)
+            eng.use_packed(0)
+            # ... nor block-max pruning of the single-term queries (found stays the list's posting count)
+            eng.build_blockmax()
+            eng.use_pruning(True)
+            h2, n2, f2, _ = eng.search_batch(gen(Q), K, flags)
+            assert hits.tobytes() == h2.tobytes() and nhits.tobytes() == n2.tobytes() and found.tobytes() == f2.tobytes(), (cfg, "pruning")
+            eng.use_pruning(False)
             if cfg in ("cfg5", "cfg3"):
                 eng.build_impacts()
                 for pk in (1, 0):
@@ -292,6 +326,125 @@ def test_full_batches_equal_oracle_and_reference_digests(index_factory):
                     assert hits.tobytes() == h2.tobytes() and nhits.tobytes() == n2.tobytes() and found.tobytes() == f2.tobytes(), (cfg, "impacts", pk)
         finally:
             eng.close()
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_blockmax_pruning_equals_exhaustive_oracle_and_reference(name, golden_index):
+    """SURVEY 8 f2, block-max scores (ns_segment_build_blockmax / ns_ctx_use_pruning): single-term queries skip the blocks
+    whose maximum cannot enter their top-K; `found` is the list's posting count.  Every golden index, K = 1 / 10 / 100, OR
+    and AND, forced splits (range items start and end inside blocks), with and without skip tables: hits, order, nhits and
+    found equal the exhaustive path's bytes, the oracle and the real reference's captured scores."""
+    g, d, _ = golden_index(name)
+    eng, ora = nsbind.Engine(d, 0), orc.Oracle(d)
+    try:
+        eng.build_blockmax()
+        vocab = g["params"]["vocab"]
+        singles = [workloads.term_name(r) for r in (1, 2, 3, 5, 8, 13, 40, 100, 300) if r <= vocab] + ["covid covid", "virus the of", "zzzz"]
+        queries = g["queries"] + singles + workloads.cfg5_queries(120, 3, vocab)
+        for k in (1, 10, 100):
+            for flags in (0, nsbind.NS_FLAG_AND):
+                want = ora.search_batch(queries, k, flags)
+                for tune in ((0, 0, 0), (0, 1, 300), (0, 4096, 0), (0, 1, 1 << 30)):
+                    eng.set_tuning(*tune)
+                    eng.use_pruning(False)
+                    plain = eng.search_batch(queries, k, flags)
+                    for skips in (True, False):
+                        eng.use_skips(skips)
+                        eng.use_pruning(True)
+                        pruned = eng.search_batch(queries, k, flags)
+                        for x, y in zip(plain, pruned):
+                            assert x.tobytes() == y.tobytes(), (name, k, flags, tune, skips)
+                    eng.use_skips(True)
+                    assert_same(pruned, want, queries, f"{name} k={k} flags={flags} tune={tune} pruned")
+        eng.set_tuning(0, 0, 0)
+        # the batch really took the pruned body, and the real reference's captured scores are reproduced with it
+        b = eng.prepare(singles, 10)
+        assert b.info().flags & nsbind.NS_INFO_PRUNED
+        b.close()
+        for case in g["cases"]:
+            gh, gn, gf, gu = eng.search_batch(g["queries"], case["k"])
+            for qi, ref in enumerate(case["results"]):
+                if ref["found"] < 0:
+                    assert not gu[qi]
+                    continue
+                assert int(gf[qi]) == ref["found"]
+                assert [int(b_) for b_ in gh[qi, : gn[qi]]["score"].view(np.uint32)] == [h[2] for h in ref["hits"]]
+    finally:
+        eng.close()
+        ora.close()
+
+
+def test_blockmax_pruning_ties_weights_and_registration():
+    """Raw C-ABI: all docs of equal length and tf, so every posting of a list scores the same (the K best are the K
+    smallest docIds: a block whose maximum EQUALS theta must be skipped, not read); a list whose best postings sit in its
+    last block; tf == 0 postings; a fractional and a negative weight (the negative one must not be pruned); a foreign idf
+    (not pruned); re-registration with another idf; a bad offset."""
+    import ctypes as C
+    L = nsbind.hip_lib()
+    ctx = C.c_void_p()
+    assert L.ns_ctx_create(0, C.byref(ctx)) == 0
+    try:
+        n_docs = 40_000
+        rng = np.random.default_rng(5)
+        doc_len = np.full(n_docs, 100, dtype=np.uint32)
+        doc_len[-300:] = 20                                   # short docs at the END: the best scores of list B are in its last blocks
+        la = np.arange(0, n_docs, 2, dtype=np.uint32)         # list A: 20000 postings, all tf 3 (equal scores but for the tail)
+        ta = np.full(la.size, 3, dtype=np.uint32)
+        lb = np.sort(rng.choice(n_docs, 9000, replace=False)).astype(np.uint32)
+        tb = rng.integers(0, 6, lb.size).astype(np.uint32)    # tf 0 .. 5 (zeros included)
+        post = np.empty((la.size + lb.size, 2), dtype=np.uint32)
+        post[:la.size, 0], post[:la.size, 1] = la, ta
+        post[la.size:, 0], post[la.size:, 1] = lb, tb
+        avgdl = float(np.float32(doc_len.astype(np.float64).sum() / n_docs))
+        seg = C.c_void_p()
+        assert L.ns_segment_upload(ctx, 0, n_docs, C.c_float(avgdl), doc_len.ctypes.data, post.ctypes.data, post.nbytes, C.byref(seg)) == 0
+        offs = np.array([0, la.size * 8], dtype=np.uint64)
+        cnts = np.array([la.size, lb.size], dtype=np.uint32)
+        idfs = np.array([1.25, 0.75], dtype=np.float32)
+        assert L.ns_segment_build_blockmax(ctx, seg, offs.ctypes.data, cnts.ctypes.data, idfs.ctypes.data, 2) == 0
+        bad = np.array([4], dtype=np.uint64)
+        assert L.ns_segment_build_blockmax(ctx, seg, bad.ctypes.data, cnts.ctypes.data, idfs.ctypes.data, 1) == -1
+
+        def run(refs, k, prune, split=0):
+            L.ns_set_tuning(ctx, 0, 1 if split else 0, split)
+            L.ns_ctx_use_pruning(ctx, 1 if prune else 0)
+            qd = np.array([(i, 1) for i in range(len(refs))], dtype=nsbind.QDESC_DTYPE)
+            tr = np.array(refs, dtype=nsbind.TERM_DTYPE)
+            b = nsbind.prepare_raw(ctx, qd, tr, k, 0)
+            b.run(timed=False); b.sync()
+            out = b.fetch() + (b.info().flags,)
+            b.close()
+            return out
+
+        def ref(seg_id, count, byte_off, idf, w):
+            return (seg_id, count, byte_off, idf, w)
+        refs = [ref(0, la.size, 0, 1.25, 1.0), ref(0, lb.size, la.size * 8, 0.75, 1.0), ref(0, lb.size, la.size * 8, 0.75, 0.37),
+                ref(0, lb.size, la.size * 8, 0.75, -1.0), ref(0, la.size, 0, 1.5, 1.0)]
+        for k in (1, 3, 10, 100):
+            for split in (0, 700, 5000):
+                h0, n0, f0, fl0 = run(refs, k, False, split)
+                h1, n1, f1, fl1 = run(refs, k, True, split)
+                assert not (fl0 & nsbind.NS_INFO_PRUNED) and (fl1 & nsbind.NS_INFO_PRUNED)
+                assert h0.tobytes() == h1.tobytes() and n0.tobytes() == n1.tobytes() and f0.tobytes() == f1.tobytes(), (k, split)
+                assert int(f1[0]) == la.size and int(f1[1]) == lb.size
+                # equal scores: the K best of list A's long docs are the smallest docIds (its short tail scores higher)
+                tail = la[la >= n_docs - 300]
+                want = list(tail[:k]) if k <= tail.size else list(tail) + list(la[: k - tail.size])
+                assert list(h1[0, :k]["doc"]) == want, (k, split)
+        # a batch made only of refs that must NOT be pruned (negative weight, foreign idf) does not take the pruned body
+        *_, fl = run([refs[3], refs[4]], 10, True)
+        assert not (fl & nsbind.NS_INFO_PRUNED)
+        # re-registration with the other idf: now that ref is pruned, and the first registration of list A no longer matches
+        idf2 = np.array([1.5], dtype=np.float32)
+        assert L.ns_segment_build_blockmax(ctx, seg, offs.ctypes.data, cnts.ctypes.data, idf2.ctypes.data, 1) == 0
+        a = run([refs[4]], 10, False); b_ = run([refs[4]], 10, True)
+        assert (b_[3] & nsbind.NS_INFO_PRUNED) and a[0].tobytes() == b_[0].tobytes() and a[2].tobytes() == b_[2].tobytes()
+        *_, fl = run([refs[0]], 10, True)
+        assert not (fl & nsbind.NS_INFO_PRUNED)
+        L.ns_set_tuning(ctx, 0, 0, 0)
+        L.ns_ctx_use_pruning(ctx, 0)
+    finally:
+        L.ns_ctx_destroy(ctx)
 
 
 def test_fixed_seed_fuzz_slice():
@@ -637,6 +790,14 @@ def test_raw_abi_weights_and_errors(engines):
     assert rc == 0
     rc, hits, nhits, found = nsbind.search_batch_raw(eng.ctx, np.array([(0, 0), (0, 2)], dtype=nsbind.QDESC_DTYPE), refs, 10)
     assert rc == 0 and nhits[0] == 0 and found[0] == 0 and nhits[1] == 10
+    # the padding the header promises — unused tail entries are {-inf, ~0, ~0} — for every K, also for a query without any
+    # term ref next to queries with partial rows (round 3: such a query's row was only padded up to entry 63)
+    for k in (1, 10, 64, 65, 100):
+        rc, hits, nhits, found = nsbind.search_batch_raw(eng.ctx, np.array([(0, 0), (0, 2), (0, 0)], dtype=nsbind.QDESC_DTYPE), refs, k)
+        assert rc == 0
+        for q in range(3):
+            tail = hits[q, nhits[q]:]
+            assert np.all(tail["doc"] == 0xFFFFFFFF) and np.all(tail["seg"] == 0xFFFFFFFF) and np.all(np.isneginf(tail["score"])), (k, q)
 
 
 def test_idf_outside_short_division_range_scales_exactly(engines):
