@@ -189,6 +189,10 @@ int ns_ctx_use_skips(ns_ctx* ctx, int on);
 int ns_segment_build_blockmax(ns_ctx* ctx, ns_seg* seg, const uint64_t* byte_off, const uint32_t* counts,
                               const float* idfs, uint32_t n_lists);
 int ns_ctx_use_pruning(ns_ctx* ctx, int on);
+/* on = 0: term groups of exactly two lists take the driver-stream body (table + probes) like every other group instead of
+ * the two-list merge body (default: on = 1; both sorted lists advance in lockstep, B's postings find their docs among A's
+ * round by a lower bound in LDS: src/api_engine.cpp:449-481 for two lists without a hash table).  Same results. */
+int ns_ctx_use_merge(ns_ctx* ctx, int on);
 
 /* ---- one-shot search (host buffers in, host buffers out) ------------------------------------ */
 /* hits_out: Q*K entries, query-major, best first: score desc, then seg_id asc, then doc_id asc

@@ -81,6 +81,8 @@ void nsh_engine_use_packed(nsh_engine* e, int on);
  * default).  Same results either way. */
 int  nsh_engine_build_blockmax(nsh_engine* e);
 void nsh_engine_use_pruning(nsh_engine* e, int on);
+/* on = 0: two-list groups take the driver-stream body instead of the merge body (ns_ctx_use_merge; default 1).  Same results. */
+void nsh_engine_use_merge(nsh_engine* e, int on);
 
 uint32_t nsh_engine_num_segments(nsh_engine* e);
 const char* nsh_engine_segment_name(nsh_engine* e, uint32_t seg);

@@ -24,6 +24,7 @@
 #include "ns_wave_kernel.hip"
 #include "ns_driver_kernel.hip"
 #include "ns_prune_kernel.hip"
+#include "ns_merge_kernel.hip"
 #include "ns_tile_kernel.hip"
 #include "ns_invert.hip"
 #include "ns_sem.hip"
@@ -155,6 +156,7 @@ struct ns_ctx {
     bool use_impacts = true;   // batches take the impact stream when every list they touch has one (ns_ctx_use_impacts)
     int use_packed = 1;        // 0 off; 1, 2: batches read the packed stream when every segment they touch has one (ns_ctx_use_packed)
     bool use_skips = true;     // doc-tile groups walk the skip grid when their lists have skip tables (ns_ctx_use_skips)
+    bool use_merge = true;     // general-class groups of exactly two term refs take the two-list merge body (ns_ctx_use_merge)
     bool use_pruning = false;  // single-term groups whose list has block maxima skip the blocks that cannot enter the top-K (ns_ctx_use_pruning)
     ns_prep* prep = nullptr;   // ns_batch_prepare's host threads and per-thread scratch, kept from batch to batch
     unsigned prep_threads = 0; // 0 = automatic (up to 8); 1 = prepare on the calling thread only (ns_ctx_set_host_threads)
@@ -214,7 +216,7 @@ static constexpr uint32_t kDefaultSplitPostings = 32768;   // forced variants: p
 // auto mode: work units per item (one unit = one streamed driver posting).  Every item pays for its own
 // top-K warm-up and its K-row partial result, so large K wants fewer, longer items (sweeps: profiles/r01).
 static constexpr uint32_t kSplitWorkSmallK = 98304, kSplitWorkLargeK = 131072;
-static constexpr uint64_t kWorkForeign = 8, kWorkTile = 2;
+static constexpr uint64_t kWorkForeign = 8, kWorkTile = 2, kWorkMerge = 4;   // merge: fitted on two-list laws (profiles/r03): 1.0 ps per unit, like the general class
 static constexpr uint32_t kSkipMinCount = 64;   // shorter lists are never looked up in the skip registry (ns_segment_build_skips)
 // per-item, per-term constants of the launch-order key (fitted to per-item timestamps, tools/dbg/item_times.py)
 static constexpr uint64_t kItemTermGeneral = 4000, kItemTermThin = 3000, kItemTermTile = 8000;   // general re-fitted in round 2 (10000 -> 4000: ab16)
@@ -276,6 +278,7 @@ extern "C" int ns_ctx_create(int device, ns_ctx** out) {
     }
     ctx->stream = ctx->own_stream;
     if (const char* om = std::getenv("NS_ORDER_MODE")) ctx->order_mode = std::atoi(om);
+    if (const char* um = std::getenv("NS_MERGE")) ctx->use_merge = std::atoi(um) != 0;
     if (const char* oc = std::getenv("NS_ORDER_COARSE")) ctx->order_coarse = std::max(0, std::min(11, std::atoi(oc)));
     if (hipStreamCreateWithFlags(&ctx->alt_stream, hipStreamNonBlocking) != hipSuccess) { ctx->alt_stream = nullptr; (void)hipGetLastError(); }
     {
@@ -894,6 +897,12 @@ extern "C" int ns_segment_build_blockmax(ns_ctx* ctx, ns_seg* seg, const uint64_
     return NS_OK;
 }
 
+extern "C" int ns_ctx_use_merge(ns_ctx* ctx, int on) {
+    if (!ctx) return NS_E_INVAL;
+    ctx->use_merge = on != 0;
+    return NS_OK;
+}
+
 extern "C" int ns_ctx_use_pruning(ns_ctx* ctx, int on) {
     if (!ctx) return NS_E_INVAL;
     ctx->use_pruning = on != 0;
@@ -1060,7 +1069,7 @@ static hipError_t batch_alloc(ns_batch* b, void** dptr, size_t n) {
 // result (descriptor bytes, launch order) is independent of the number of threads.
 namespace {
 
-struct HostGroup { DevGroup g; uint32_t query; uint64_t cost; uint64_t cmax; uint64_t work; bool wave; uint8_t cls; bool fast_div; bool signed_in; bool grid; };
+struct HostGroup { DevGroup g; uint32_t query; uint64_t cost; uint64_t cmax; uint64_t work; bool wave; uint8_t cls; bool fast_div; bool signed_in; bool grid; bool merge2; };
 
 constexpr uint32_t kOrderBuckets = 2048;   // launch-order key: 6 bits of exponent x 5 bits of mantissa of the estimated run time
 inline uint32_t order_bucket(uint64_t c) {  // descending: bucket 0 holds the longest items
@@ -1250,6 +1259,11 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                     // work estimate in units of one streamed driver posting (measured, profiles/r01): a foreign
                     // posting (claim, accumulate, read back) costs ~8x, a doc-tile posting ~2x
                     hg.work = !auto_mode ? hg.cost : (hg.cls == 2 ? hg.cost * kWorkTile : hg.cmax + rest * kWorkForeign);
+                    // two lists, general class: the merge body (no table): both lists cost about alike per posting
+                    // (two COMPARABLE lists: when one is more than 8x the other, a window of the short one per round of the long
+                    // one is mostly padding and the table path is as good: r8 + r300, 37 : 1, measured 3 % slower with the merge)
+                    hg.merge2 = auto_mode && ctx->use_merge && hg.cls == 0 && hg.g.term_count == 2 && rest * 8 >= hg.cmax;
+                    if (hg.merge2) hg.work = hg.cmax + rest * kWorkMerge;
                 }
                 if (!hg.wave) {
                     hg.g.bounds_off = S.bounds_total;   // local; the slice's base is added in phase B
@@ -1402,7 +1416,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                         it.out_slot = S.n_rows++;
                         it.whole = (ns == 1 ? 1u : 0u) | (hg.fast_div ? 8u : 0u) | (hg.signed_in ? 16u : 0u) | (hg.grid ? (hg.cls == 2 ? 32u : 64u) : 0u);
                         // auto mode: very dense groups take the doc-tile body (bit 1), groups with thin non-driver lists the small foreign budget (bit 2)
-                        if (auto_mode) it.whole |= (hg.cls == 2 ? 2u : 0u) | (hg.cls == 1 ? 4u : 0u) | (pruned ? 128u : 0u);
+                        if (auto_mode) it.whole |= (hg.cls == 2 ? 2u : 0u) | (hg.cls == 1 ? 4u : 0u) | (pruned ? 128u : 0u) | (hg.merge2 && hg.wave ? 256u : 0u);
                         S.witems.push_back(it);
                         S.wbucket.push_back((uint16_t)(bucket | (wide ? 0x8000u : 0u)));
                         {
@@ -1993,80 +2007,103 @@ static int invert_run(ns_ctx* ctx, const uint32_t* doc_term_counts, uint32_t n_d
     hipStream_t st = ctx->stream;
     const uint32_t n = (uint32_t)n_pairs;
     const uint32_t n_tiles = (n + kIvTile - 1) / kIvTile;
-    const size_t m = (size_t)256 * n_tiles;                 // histogram counters per pass
-    const uint32_t scan_blocks = (uint32_t)((m + 1023) / 1024);
+    // Digit plan, from n_terms alone (no device -> host sync decides it): the largest key is n_terms itself (the pairs the
+    // reference drops, src/lexicon.cpp:69-70); `bits` bits in ceil(bits / 11) passes of 8 .. 11 bits, as even as possible.
     int bits = 1;
-    while (bits < 32 && (n_terms >> bits) != 0) bits++;     // the largest key is n_terms itself
-    int passes = (bits + 7) / 8;
+    while (bits < 32 && (n_terms >> bits) != 0) bits++;
+    const int passes = std::max(1, (bits + 10) / 11);
+    int pbits[3] = {8, 8, 8};
+    {
+        int left = bits;
+        for (int p = 0; p < passes; p++) {
+            const int share = (left + (passes - p) - 1) / (passes - p);
+            pbits[p] = std::min(11, std::max(8, share));
+            left -= pbits[p];
+            if (left < 0) left = 0;
+        }
+    }
+    size_t m_max = 0;
+    for (int p = 0; p < passes; p++) m_max = std::max(m_max, ((size_t)1 << pbits[p]) * n_tiles);
+    const uint32_t scan_blocks_max = (uint32_t)((m_max + 1023) / 1024);
 
     // one block from the ctx pool for all scratch arrays (a build loop inverts segment after segment of similar size;
     // ten hipMalloc + hipFree per call cost more than the device work)
     uint2 *d_pairs = nullptr, *d_vals[2] = {nullptr, nullptr};
-    uint32_t *d_keys[2] = {nullptr, nullptr}, *d_df = nullptr, *d_first = nullptr, *d_hist = nullptr, *d_sums = nullptr;
+    uint32_t *d_keys[2] = {nullptr, nullptr}, *d_df = nullptr, *d_hist = nullptr, *d_sums = nullptr;
     uint64_t* d_prefix = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipError_t e = hipSuccess;
     auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
     size_t off = 0;
     auto place = [&](size_t bytes) { const size_t o = off; off = (off + std::max<size_t>(bytes, 1) + 255) & ~(size_t)255; return o; };
-    const size_t nt1 = (size_t)std::max<uint32_t>(n_terms, 1);
-    const size_t o_pairs = place((size_t)n * 8), o_v0 = place((size_t)n * 8), o_v1 = place((size_t)n * 8), o_k0 = place((size_t)n * 4), o_k1 = place((size_t)n * 4);
-    const size_t o_df = place(nt1 * 4), o_first = place(nt1 * 4), o_hist = place(m * 4), o_sums = place((size_t)scan_blocks * 4), o_prefix = place(prefix.size() * 8);
+    const size_t o_pairs = place((size_t)n * 8), o_v0 = place((size_t)n * 8), o_v1 = place(passes > 1 ? (size_t)n * 8 : 1);
+    const size_t o_k0 = place(passes > 1 ? (size_t)n * 4 : 1), o_k1 = place(passes > 2 ? (size_t)n * 4 : 1);
+    const size_t o_df = place(((size_t)n_terms + 1) * 4), o_hist = place(m_max * 4), o_sums = place((size_t)scan_blocks_max * 4), o_prefix = place(prefix.size() * 8);
     const size_t block_bytes = off;
     char* blk = nullptr;
     chk(pool_alloc(ctx, (void**)&blk, block_bytes));
     if (e == hipSuccess) {
         d_pairs = (uint2*)(blk + o_pairs); d_vals[0] = (uint2*)(blk + o_v0); d_vals[1] = (uint2*)(blk + o_v1);
         d_keys[0] = (uint32_t*)(blk + o_k0); d_keys[1] = (uint32_t*)(blk + o_k1);
-        d_df = (uint32_t*)(blk + o_df); d_first = (uint32_t*)(blk + o_first); d_hist = (uint32_t*)(blk + o_hist); d_sums = (uint32_t*)(blk + o_sums);
+        d_df = (uint32_t*)(blk + o_df); d_hist = (uint32_t*)(blk + o_hist); d_sums = (uint32_t*)(blk + o_sums);
         d_prefix = (uint64_t*)(blk + o_prefix);
     }
     chk(hipEventCreate(&ev0));
     chk(hipEventCreate(&ev1));
+    uint2* d_final = nullptr;
     if (e == hipSuccess) {
         chk(hipMemcpyAsync(d_pairs, pairs, (size_t)n * 8, hipMemcpyHostToDevice, st));
         chk(hipMemcpyAsync(d_prefix, prefix.data(), prefix.size() * 8, hipMemcpyHostToDevice, st));
-        chk(hipMemsetAsync(d_df, 0, (size_t)std::max<uint32_t>(n_terms, 1) * 4, st));
-        chk(hipMemsetAsync(d_sums, 0, 4, st));   // k_iv_expand counts the dropped pairs here before the scans use it
+        chk(hipMemsetAsync(d_df, 0, ((size_t)n_terms + 1) * 4, st));
         chk(hipEventRecord(ev0, st));
-        hipLaunchKernelGGL(k_iv_expand, dim3(n_tiles), dim3(256), 0, st, d_pairs, d_prefix, n_docs, n, n_terms, d_keys[0], d_vals[0], d_sums);
-        // the key n_terms exists only if some pair was dropped: without it the keys are < n_terms (one bit, often one pass, less)
-        uint32_t dropped = 0;
-        chk(hipMemcpyAsync(&dropped, d_sums, 4, hipMemcpyDeviceToHost, st));
-        chk(hipStreamSynchronize(st));
-        if (e == hipSuccess && dropped == 0 && n_terms > 1) {
-            bits = 1;
-            while (bits < 32 && ((n_terms - 1) >> bits) != 0) bits++;
-            passes = (bits + 7) / 8;
-        }
-        int cur = 0;
+        // pass p reads (p == 0: the pairs; else keys / vals buffer `cur`) and writes buffer `nxt`; the last pass writes vals only
+        int cur = -1;
+        uint32_t shift = 0;
         for (int p = 0; p < passes; p++) {
-            const uint32_t shift = (uint32_t)p * 8;
-            hipLaunchKernelGGL(k_iv_hist, dim3(n_tiles), dim3(256), 0, st, d_keys[cur], n, shift, d_hist, n_tiles);
+            const bool first = p == 0, last = p == passes - 1;
+            const int nxt = first ? 0 : (cur ^ 1);
+            const size_t m = ((size_t)1 << pbits[p]) * n_tiles;
+            const uint32_t scan_blocks = (uint32_t)((m + 1023) / 1024);
+            const uint32_t* kin = first ? nullptr : d_keys[cur];
+            const uint2* vin = first ? nullptr : d_vals[cur];
+            uint2* vout = d_vals[nxt];
+            uint32_t* kout = last ? nullptr : d_keys[nxt];
+#define NS_IV_HIST(B) hipLaunchKernelGGL((k_iv_hist_w<B>), dim3(n_tiles), dim3(256), 0, st, kin, first ? d_pairs : (const uint2*)nullptr, n, n_terms, shift, d_hist, n_tiles)
+#define NS_IV_PASS3(B, F, L) hipLaunchKernelGGL((k_iv_pass<B, F, L>), dim3(n_tiles), dim3(256), 0, st, d_pairs, d_prefix, n_docs, n_terms, kin, vin, kout, vout, n, shift, d_hist, n_tiles, d_df)
+#define NS_IV_PASS(B) { if (first && last) NS_IV_PASS3(B, true, true); else if (first) NS_IV_PASS3(B, true, false); else if (last) NS_IV_PASS3(B, false, true); else NS_IV_PASS3(B, false, false); }
+            switch (pbits[p]) {
+                case 8: NS_IV_HIST(8); break;
+                case 9: NS_IV_HIST(9); break;
+                case 10: NS_IV_HIST(10); break;
+                default: NS_IV_HIST(11); break;
+            }
             hipLaunchKernelGGL(k_iv_scan_sums, dim3(scan_blocks), dim3(256), 0, st, d_hist, (uint32_t)m, d_sums);
             hipLaunchKernelGGL(k_iv_scan_top, dim3(1), dim3(1024), 0, st, d_sums, scan_blocks);
             hipLaunchKernelGGL(k_iv_scan_apply, dim3(scan_blocks), dim3(256), 0, st, d_hist, (uint32_t)m, d_sums);
-            hipLaunchKernelGGL(k_iv_scatter, dim3(n_tiles), dim3(256), 0, st, d_keys[cur], d_vals[cur], d_keys[cur ^ 1], d_vals[cur ^ 1], n, shift, d_hist, n_tiles);
-            cur ^= 1;
+            switch (pbits[p]) {
+                case 8: NS_IV_PASS(8); break;
+                case 9: NS_IV_PASS(9); break;
+                case 10: NS_IV_PASS(10); break;
+                default: NS_IV_PASS(11); break;
+            }
+#undef NS_IV_HIST
+#undef NS_IV_PASS
+#undef NS_IV_PASS3
+            shift += (uint32_t)pbits[p];
+            cur = nxt;
         }
-        std::vector<uint32_t> h_first(n_terms);
-        if (n_terms) {   // d_df holds the runs' last positions, 0xFFFFFFFF in d_first marks a term without postings
-            chk(hipMemsetAsync(d_first, 0xFF, (size_t)n_terms * 4, st));
-            hipLaunchKernelGGL(k_iv_runs, dim3((n + 255) / 256), dim3(256), 0, st, d_keys[cur], n, n_terms, d_first, d_df);
-        }
+        d_final = d_vals[cur];
         chk(hipEventRecord(ev1, st));
         chk(hipGetLastError());
         if (n_terms) chk(hipMemcpyAsync(df_out, d_df, (size_t)n_terms * 4, hipMemcpyDeviceToHost, st));
-        if (n_terms) chk(hipMemcpyAsync(h_first.data(), d_first, (size_t)n_terms * 4, hipMemcpyDeviceToHost, st));
         chk(hipStreamSynchronize(st));
         if (e == hipSuccess) {
             uint64_t kept = 0;
-            for (uint32_t t = 0; t < n_terms; t++) df_out[t] = (h_first[t] == 0xFFFFFFFFu) ? 0u : df_out[t] - h_first[t] + 1u;
             for (uint32_t t = 0; t < n_terms; t++) kept += df_out[t];
-            *kept_out = kept;   // the dropped pairs carry the largest key: they sort behind every list
-            if (kept && postings_out) chk(hipMemcpy(postings_out, d_vals[cur], (size_t)kept * 8, hipMemcpyDeviceToHost));
+            *kept_out = kept;   // the dropped pairs carry the largest key: they sort behind every list and are not written
+            if (kept && postings_out) chk(hipMemcpy(postings_out, d_final, (size_t)kept * 8, hipMemcpyDeviceToHost));
             if (adopt) {   // the lists stay on the device: they ARE the segment's posting stream
-                if (kept) chk(hipMemcpyAsync(adopt->d_postings, d_vals[cur], (size_t)kept * 8, hipMemcpyDeviceToDevice, st));
+                if (kept) chk(hipMemcpyAsync(adopt->d_postings, d_final, (size_t)kept * 8, hipMemcpyDeviceToDevice, st));
                 if (kept != adopt->n_postings) {   // dropped pairs: the stream is shorter than announced; move the padding
                     chk(hipMemsetAsync((char*)adopt->d_postings + kept * 8, 0xFF, kPadPostings * 8, st));
                     chk(hipMemsetAsync((char*)adopt->d_pnorm + kept * 4, 0, kPadPostings * 4, st));

@@ -98,6 +98,7 @@ struct DevWItem {
                            //        and the terms with DevTerm::skip != 0 take their postings of a tile from the skip table
                            // bit 6: driver-stream bodies: doc_lo (and doc_hi, unless it is n_docs) are multiples of kSkipDocs, and the
                            //        terms with DevTerm::skip != 0 take the range's ends in their lists from the skip table
+                           // bit 8: two-list MERGE body (ns_merge_kernel.hip): the group has exactly two term refs; no table
                            // bit 7: PRUNED single-term item (ns_ctx_use_pruning): the group's one list has block maxima (DevTerm::bmx);
                            //        blocks whose best possible score cannot enter the item's top-K are not read; `found` is the
                            //        number of the list's postings in the doc range (one list: every posting is a doc of its own)

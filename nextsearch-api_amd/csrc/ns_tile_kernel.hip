@@ -20,6 +20,7 @@
 #include "ns_wave_kernel.hip"
 #include "ns_driver_kernel.hip"
 #include "ns_prune_kernel.hip"
+#include "ns_merge_kernel.hip"
 
 namespace ns {
 
@@ -456,9 +457,13 @@ __global__ void __launch_bounds__(64 * kUscoreWavesPerBlock) __attribute__((amdg
     const bool tiles = (it.whole & 2u) != 0;
     const bool thin = (it.whole & 4u) != 0;   // the non-driver lists are thin: smallest foreign budget
     const bool pruned = (it.whole & 128u) != 0;   // single-term item with block maxima (ns_ctx_use_pruning)
+    const bool merge2 = (it.whole & 256u) != 0;   // two-list group: the merge body (ns_ctx_use_merge)
     it.whole &= 121u;   // bit 0: whole segment, bit 3: short division, bit 4: signed inputs, bits 5 / 6: skip grid (doc tiles / range ends)
     if (pruned)
         pscore_body<AND, CB>(it, terms, segs, s_cand[wave], out_hits, out_nhits, out_found, K, lane);
+    else if (merge2)
+        mscore_body<AND, CB>(it, terms, segs, s_tbl[wave], reinterpret_cast<float*>(s_tbl[wave] + 256), s_cand[wave],
+                             out_hits, out_nhits, out_found, K, lane);
     else if (thin)
         dscore_body<HK / 2, 64, AND, CB, IMP, PK>(it, terms, segs, s_tbl[wave], s_vals[wave], s_mcnt[wave], s_cand[wave],
                                  s_tab[wave], s_aux[wave], out_hits, out_nhits, out_found, K, lane);

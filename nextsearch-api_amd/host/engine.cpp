@@ -290,6 +290,12 @@ void Engine::use_pruning(bool on) {
     for (auto& r : replicas_) ns_ctx_use_pruning(r.ctx, on ? 1 : 0);
 }
 
+void Engine::use_merge(bool on) {
+    std::lock_guard<std::recursive_mutex> lock(mtx_);
+    if (ctx_) ns_ctx_use_merge(ctx_, on ? 1 : 0);
+    for (auto& r : replicas_) ns_ctx_use_merge(r.ctx, on ? 1 : 0);
+}
+
 void Engine::use_packed(int mode) {
     std::lock_guard<std::recursive_mutex> lock(mtx_);
     if (ctx_) ns_ctx_use_packed(ctx_, mode);
@@ -463,10 +469,19 @@ bool Engine::search_batch(const std::vector<std::string>& queries, int k, uint32
     return search_batch_locked(queries, k, flags, out);
 }
 
-// Sub-batches of a large batch (search_batch_flat): big enough to keep the device near its full-batch rate (a 4096-query
-// batch of the cfg5 law runs at 85 % of a 16384-query batch's rate), small enough that preparing the first
-// one — the only host work the device does not hide — is a small part of the call.
-static constexpr size_t kSubBatch = 4096;
+// Sub-batches of a large batch (search_batch_flat): big enough to keep the device near its full-batch rate, small enough
+// that preparing the first one — the only host work the device does not hide — is a small part of the call.  Measured on
+// cfg5's 16384 queries (profiles/r03, ns_tool facade-bench): sub-batches of 2048 / 4096 / 5462 / 8192 / no cut =
+// 8.4 / 5.0 / 4.6 / 3.65 / 3.83 ms per call.
+static constexpr size_t kSubBatchDefault = 8192;
+static size_t sub_batch_size() {   // NS_SUBBATCH overrides it (experiments)
+    static const size_t v = []() {
+        const char* e = std::getenv("NS_SUBBATCH");
+        const long n = e ? std::atol(e) : 0;
+        return n >= 64 ? (size_t)n : kSubBatchDefault;
+    }();
+    return v;
+}
 
 // One contiguous range [q0, q1) of a batch on one context.  Two or more sub-batches: prepare(i + 1) on the host || kernels(i)
 // on the device || results(i - 1) on their way back.  pooled_prep: query preparation on the engine's host threads (the one
@@ -475,6 +490,7 @@ bool Engine::run_range(ns_ctx* ctx, const QueryView* queries, size_t q0, size_t 
                        uint64_t* found, uint8_t* usable, bool pooled_prep, std::string& err) {
     const size_t Q = q1 - q0;
     if (Q == 0) return true;
+    const size_t kSubBatch = sub_batch_size();
     const size_t n_sub = Q >= 2 * kSubBatch ? (Q + kSubBatch - 1) / kSubBatch : 1;
     const bool piped = n_sub > 1;
     if (piped) (void)ns_ctx_set_overlap(ctx, 1);

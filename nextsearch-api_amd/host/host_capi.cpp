@@ -4,6 +4,7 @@
 #include "invert.hpp"
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -14,13 +15,19 @@
 
 struct nsh_engine {
     nextsearch::Engine eng;
-    std::string err;
+    std::string err;      // the wrapper's last message; written and read under err_mtx (callers may share an engine between threads)
+    std::mutex err_mtx;
     explicit nsh_engine(int device) : eng(device) {}
     explicit nsh_engine(const std::vector<int>& devices) : eng(devices) {}
 };
 
+static void nsh_set_err(nsh_engine* e, const std::string& msg) {
+    if (!e) return;
+    std::lock_guard<std::mutex> l(e->err_mtx);
+    e->err = msg;
+}
 static void nsh_note(nsh_engine* e, const char* where, const char* what) {
-    if (e) e->err = std::string(where) + ": " + what;
+    nsh_set_err(e, std::string(where) + ": " + what);
 }
 #define NSH_CATCH(e, where, failval)                                                        \
     catch (const std::exception& ex_) { nsh_note((e), (where), ex_.what()); return failval; } \
@@ -58,7 +65,7 @@ extern "C" int nsh_engine_open(const char* index_dir, int device, nsh_engine** o
     nsh_engine* e = new nsh_engine(device);
     e->eng.index_dir = index_dir ? index_dir : "";
     *out = e;
-    if (!e->eng.reload()) { e->err = e->eng.last_error(); return -1; }
+    if (!e->eng.reload()) { nsh_set_err(e, e->eng.last_error()); return -1; }
     return 0;
 } NSH_CATCH(out ? *out : nullptr, "nsh_engine_open", -1)
 }
@@ -68,7 +75,7 @@ extern "C" int nsh_engine_open_multi(const char* index_dir, const int* devices, 
     nsh_engine* e = new nsh_engine(std::vector<int>(devices, devices + n_devices));
     e->eng.index_dir = index_dir ? index_dir : "";
     *out = e;
-    if (!e->eng.reload()) { e->err = e->eng.last_error(); return -1; }
+    if (!e->eng.reload()) { nsh_set_err(e, e->eng.last_error()); return -1; }
     return 0;
 } NSH_CATCH(out ? *out : nullptr, "nsh_engine_open_multi", -1)
 }
@@ -85,14 +92,21 @@ extern "C" void nsh_engine_close(nsh_engine* e) { delete e; }
 // keeps serving what it served before and nsh_engine_error() says why.
 extern "C" int nsh_engine_reload(nsh_engine* e) { try {
     if (!e) return -1;
-    if (!e->eng.reload()) { e->err = e->eng.last_error(); return -1; }
+    if (!e->eng.reload()) { nsh_set_err(e, e->eng.last_error()); return -1; }
     return 0;
 } NSH_CATCH(e, "nsh_engine_reload", -1)
 }
 extern "C" const char* nsh_engine_error(nsh_engine* e) { try {
     if (!e) return "null engine";
-    if (!e->eng.last_error().empty()) e->err = e->eng.last_error();
-    return e->err.c_str();
+    // a copy per calling thread: the pointer stays valid until this thread asks again, whatever other threads do
+    thread_local std::string mine;
+    const std::string eng_err = e->eng.last_error();
+    {
+        std::lock_guard<std::mutex> l(e->err_mtx);
+        if (!eng_err.empty()) e->err = eng_err;
+        mine = e->err;
+    }
+    return mine.c_str();
 } NSH_CATCH(e, "nsh_engine_error", "")
 }
 extern "C" ns_ctx* nsh_engine_ctx(nsh_engine* e) { try { return e ? e->eng.ctx() : nullptr;  } NSH_CATCH(e, "nsh_engine_ctx", nullptr)
@@ -129,7 +143,7 @@ extern "C" int nsh_engine_hits_to_json(nsh_engine* e, const char* query, int k, 
     r.found = found;
     if (nhits && !hits) return -1;
     for (uint32_t i = 0; i < nhits; i++) {
-        if (hits[i].seg_id >= e->eng.segments.size()) { e->err = "nsh_engine_hits_to_json: hit names a segment that is not loaded"; return -1; }
+        if (hits[i].seg_id >= e->eng.segments.size()) { nsh_set_err(e, "nsh_engine_hits_to_json: hit names a segment that is not loaded"); return -1; }
         r.hits.push_back(nextsearch::SearchHit{hits[i].score, hits[i].seg_id, hits[i].doc_id});
     }
     const std::string js = e->eng.to_json(r);
@@ -221,7 +235,7 @@ extern "C" int nsh_engine_search_json(nsh_engine* e, const char* query, int k, c
     if (!e || !json_out) return -1;
     std::string s;
     const bool ok = e->eng.search_text(query ? query : "", k, s);   // Engine::search: the result cache included
-    if (!ok) { e->err = e->eng.last_error(); *json_out = nullptr; return -1; }
+    if (!ok) { nsh_set_err(e, e->eng.last_error()); *json_out = nullptr; return -1; }
     *json_out = (char*)std::malloc(s.size() + 1);
     std::memcpy(*json_out, s.c_str(), s.size() + 1);
     return 0;
@@ -234,7 +248,7 @@ extern "C" int nsh_engine_search_batch_json(nsh_engine* e, const char* const* qu
                                             char** text_out, uint64_t* offsets) { try {
     if (!e || !text_out || !offsets) return -1;
     std::vector<std::string> qs = to_vec(queries, n_queries), bodies;
-    if (!e->eng.search_batch_json(qs, k, bodies)) { e->err = e->eng.last_error(); return -1; }
+    if (!e->eng.search_batch_json(qs, k, bodies)) { nsh_set_err(e, e->eng.last_error()); return -1; }
     size_t total = 0;
     for (auto& b : bodies) total += b.size();
     char* buf = (char*)std::malloc(total + 1);
@@ -268,7 +282,7 @@ extern "C" int nsh_engine_search_batch(nsh_engine* e, const char* const* queries
     if (!nhits) { n_.resize(n_queries); nhits = n_.data(); }
     if (!found) { f_.resize(n_queries); found = f_.data(); }
     if (!has_found) { u_.resize(n_queries); has_found = u_.data(); }
-    if (!e->eng.search_batch_flat(views.data(), n_queries, k, flags, hits, nhits, found, has_found)) { e->err = e->eng.last_error(); return -1; }
+    if (!e->eng.search_batch_flat(views.data(), n_queries, k, flags, hits, nhits, found, has_found)) { nsh_set_err(e, e->eng.last_error()); return -1; }
     for (uint32_t q = 0; q < n_queries; q++) {
         if (has_found[q]) continue;   // the early return (src/api_engine.cpp:407): no hits, no found
         nhits[q] = 0; found[q] = 0;
@@ -317,7 +331,7 @@ extern "C" int nsh_engine_semantic_row(nsh_engine* e, uint32_t row, const char**
 extern "C" int nsh_engine_expand(nsh_engine* e, const char* query, char** text_out) { try {
     if (!e || !query || !text_out) return -1;
     std::vector<nsx::WeightedTerms> w;
-    if (!e->eng.expand_queries({std::string(query)}, w)) { e->err = e->eng.last_error(); return -1; }
+    if (!e->eng.expand_queries({std::string(query)}, w)) { nsh_set_err(e, e->eng.last_error()); return -1; }
     std::string o;
     char buf[16];
     for (const auto& tw : w[0]) {
@@ -341,13 +355,13 @@ extern "C" uint32_t nsh_engine_cache_size(nsh_engine* e) { try { return e ? (uin
 
 extern "C" int nsh_engine_build_impacts(nsh_engine* e) { try {
     if (!e) return -1;
-    if (!e->eng.build_impacts()) { e->err = e->eng.last_error(); return -1; }
+    if (!e->eng.build_impacts()) { nsh_set_err(e, e->eng.last_error()); return -1; }
     return 0;
 } NSH_CATCH(e, "nsh_engine_build_impacts", -1)
 }
 extern "C" int nsh_engine_build_packed(nsh_engine* e) { try {
     if (!e) return -1;
-    if (!e->eng.build_packed()) { e->err = e->eng.last_error(); return -1; }
+    if (!e->eng.build_packed()) { nsh_set_err(e, e->eng.last_error()); return -1; }
     return 0;
 } NSH_CATCH(e, "nsh_engine_build_packed", -1)
 }
@@ -355,11 +369,13 @@ extern "C" void nsh_engine_use_packed(nsh_engine* e, int on) { try { if (e) e->e
 }
 extern "C" int nsh_engine_build_blockmax(nsh_engine* e) { try {
     if (!e) return -1;
-    if (!e->eng.build_blockmax()) { e->err = e->eng.last_error(); return -1; }
+    if (!e->eng.build_blockmax()) { nsh_set_err(e, e->eng.last_error()); return -1; }
     return 0;
 } NSH_CATCH(e, "nsh_engine_build_blockmax", -1)
 }
 extern "C" void nsh_engine_use_pruning(nsh_engine* e, int on) { try { if (e) e->eng.use_pruning(on != 0); } NSH_CATCH_VOID(e, "nsh_engine_use_pruning")
+}
+extern "C" void nsh_engine_use_merge(nsh_engine* e, int on) { try { if (e) e->eng.use_merge(on != 0); } NSH_CATCH_VOID(e, "nsh_engine_use_merge")
 }
 extern "C" void nsh_engine_use_skips(nsh_engine* e, int on) { try { if (e) e->eng.use_skips(on != 0);  } NSH_CATCH_VOID(e, "nsh_engine_use_skips")
 }
@@ -369,7 +385,7 @@ extern "C" void nsh_engine_use_impacts(nsh_engine* e, int on) { try { if (e) e->
 extern "C" int nsh_engine_prepare(nsh_engine* e, const char* const* queries, uint32_t n_queries, int k, uint32_t flags,
                                   ns_batch** out) { try {
     if (!e || !out) return -1;
-    if (!e->eng.prepare(to_vec(queries, n_queries), k, flags, out)) { e->err = e->eng.last_error(); return -1; }
+    if (!e->eng.prepare(to_vec(queries, n_queries), k, flags, out)) { nsh_set_err(e, e->eng.last_error()); return -1; }
     return 0;
 } NSH_CATCH(e, "nsh_engine_prepare", -1)
 }

@@ -374,6 +374,41 @@ def test_blockmax_pruning_equals_exhaustive_oracle_and_reference(name, golden_in
         ora.close()
 
 
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_two_list_merge_body_equals_table_body_oracle_and_reference(name, golden_index):
+    """north_star "intersect/merge across query terms": groups of exactly two lists advance through both sorted lists in
+    lockstep (ns_merge_kernel.hip) instead of hashing one into a table.  Two-term queries of every shape — hot + hot, hot +
+    rare, rare + rare, the same term twice (both lists ARE the same list: every doc matches), a term the lexicon lacks —
+    in OR and AND mode, K = 1 / 10 / 100, forced splits: equal to the driver-stream body's bytes, to the oracle, and (the
+    goldens' own two-term queries) to the real reference's captured scores."""
+    g, d, _ = golden_index(name)
+    eng, ora = nsbind.Engine(d, 0), orc.Oracle(d)
+    try:
+        vocab = g["params"]["vocab"]
+        T = workloads.term_name
+        rng = np.random.default_rng(17)
+        pairs = [f"{T(a)} {T(b)}" for a, b in ((1, 2), (2, 1), (3, 40), (40, 3), (8, 9), (100, 101), (5, 5), (60, 60), (1, vocab), (vocab, 2))]
+        pairs += [f"{T(int(a))} {T(int(b))}" for a, b in zip(rng.integers(1, min(vocab, 64), 60), rng.integers(1, vocab, 60))]
+        pairs += ["covid zzzz", "zzzz covid", "virus the vaccine"]
+        queries = g["queries"] + pairs
+        for k in (1, 10, 100):
+            for flags in (0, nsbind.NS_FLAG_AND):
+                want = ora.search_batch(queries, k, flags)
+                for tune in ((0, 0, 0), (0, 1, 300), (0, 4096, 0), (0, 1, 1 << 30)):
+                    eng.set_tuning(*tune)
+                    eng.use_merge(False)
+                    table = eng.search_batch(queries, k, flags)
+                    eng.use_merge(True)
+                    merged = eng.search_batch(queries, k, flags)
+                    for x, y in zip(table, merged):
+                        assert x.tobytes() == y.tobytes(), (name, k, flags, tune)
+                    assert_same(merged, want, queries, f"{name} k={k} flags={flags} tune={tune} merge body")
+        eng.set_tuning(0, 0, 0)
+    finally:
+        eng.close()
+        ora.close()
+
+
 def test_blockmax_pruning_ties_weights_and_registration():
     """Raw C-ABI: all docs of equal length and tf, so every posting of a list scores the same (the K best are the K
     smallest docIds: a block whose maximum EQUALS theta must be skipped, not read); a list whose best postings sit in its

@@ -92,10 +92,16 @@ def _run(rng, t0, last, cases, tmp, seconds, max_cases, verbose):
                 eng.use_packed(pk)
                 skips = rng.random() < 0.75     # reload() builds skip tables for the frequent lists; searches may ignore them
                 eng.use_skips(skips)
+                merge = rng.random() < 0.7      # two-list groups: merge body or driver-stream body
+                eng.use_merge(merge)
+                prune = rng.random() < 0.3      # single-term queries: block-max pruning
+                if prune:
+                    eng.build_blockmax()
+                eng.use_pruning(prune)
                 bad = same(eng.search_batch(qs, k, flags), ora.search_batch(qs, k, flags, threads=8))
                 if bad:
                     return cases, (f"MISMATCH {bad}: index(nseg={nseg}, docs={docs}, vocab={vocab}, seed={seed}) law={law} nq={nq} k={k} "
-                                   f"flags={flags} tune={tune} impacts={imp} packed={pk} skips={skips} queries={qs[:5]}")
+                                   f"flags={flags} tune={tune} impacts={imp} packed={pk} skips={skips} merge={merge} prune={prune} queries={qs[:5]}")
                 cases += 1
                 if verbose and time.time() - last > 30:
                     last = time.time()

@@ -60,6 +60,11 @@ def laws():
     for c in ("thin", "tile", "gen"):
         L["cfg5_2hot_" + c] = ([q for q in L["cfg5_2hot"][0] if cls_of(q) == c], 10)
         L["cfg5_" + c] = ([q for q in q5 if cls_of(q) == c], 10)
+    L["cfg5_t2_gen"] = ([q for q in q5 if len(q.split()) == 2 and cls_of(q) == "gen"], 10)   # two-list groups of the general class: the merge body's
+    L["r8r20"] = ([T(8) + " " + T(20)] * 4096, 10)
+    L["r20r8"] = ([T(20) + " " + T(8)] * 4096, 10)
+    L["r40r60"] = ([T(40 + i % 7) + " " + T(60 + i % 11) for i in range(8192)], 10)
+    L["r8r300"] = ([T(8) + " " + T(300 + i % 50) for i in range(4096)], 10)
     L["cfg5_1hot_gen"] = ([q for q in L["cfg5_1hot"][0] if cls_of(q) == "gen"], 10)
     L["cfg5_nohot_gen"] = ([q for q in L["cfg5_nohot"][0] if cls_of(q) == "gen"], 10)
     L["cfg3"] = (workloads.cfg3_queries(), 100)
@@ -87,6 +92,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--impacts", action="store_true", help="build the optional impact streams first")
     ap.add_argument("--packed", type=int, default=0, help="build the packed posting streams first and read them in this mode (1: norms from the fp32 stream, 2: through the 16-bit norm index)")
+    ap.add_argument("--prune", action="store_true", help="build block maxima and let single-term queries skip blocks (ns_ctx_use_pruning)")
     ap.add_argument("--no-skips", action="store_true", help="ignore the skip tables reload() built")
     ap.add_argument("--segments", type=int, default=1, help="segments of --docs docs each (20 x 1M docs = 1.1 GB of postings: beyond the 256 MiB Infinity Cache)")
     ap.add_argument("--docs", type=int, default=1_000_000)
@@ -104,13 +110,16 @@ def main():
         eng.use_packed(args.packed)
     if args.no_skips:
         eng.use_skips(False)
+    if args.prune:
+        eng.build_blockmax()
+        eng.use_pruning(True)
     L = laws()
     # every list of ranks 1..4096 scanned by exactly one query: each posting byte is read once per launch
     if args.qscale != 1.0:
         L = {n: (qs[:max(1, int(len(qs) * args.qscale))], k) for n, (qs, k) in L.items()}
     L["scan_once"] = ([T(r) for r in range(1, 4097)], 10)
     names = [n for n in args.laws.split(",") if n] or list(L.keys())
-    print(f"variant={args.variant} split={args.split} impacts={args.impacts} packed={args.packed} segments={args.segments} docs={args.docs} qscale={args.qscale}")
+    print(f"variant={args.variant} split={args.split} prune={args.prune} impacts={args.impacts} packed={args.packed} segments={args.segments} docs={args.docs} qscale={args.qscale}")
     print(f"{'law':>14} {'Q':>6} {'post/q':>9} {'items':>7} {'kern_ms':>9} {'ns/post':>8} {'GB/s':>8} {'frac':>6} {'all_ms':>8}")
     for n in names:
         qs, k = L[n]
