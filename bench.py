@@ -453,10 +453,33 @@ def main():
         assert same, "pruned results differ from the exhaustive path"
         k3 = inf3.sum_score_kernel_ms / max(inf3.timed_runs, 1)
         single = int((np.asarray(qd["term_count"]) == nseg).sum()) if nseg == 1 else None
+        # the same two ways for the batch's single-term queries ALONE (in the full batch they are not what finishes last, so
+        # the batch's time hardly moves; a batch of them shows what the skipped blocks are worth)
+        subset = None
+        st_queries = [q for q in queries if len(q.split()) == 1]
+        if len(st_queries) >= 64:
+            sqd, srefs, _ = eng.build_refs(st_queries)
+            times = {}
+            for mode in (False, True):
+                eng.use_pruning(mode)
+                sb = nsbind.prepare_raw(eng.ctx, sqd, srefs, K, flags)
+                for _ in range(args.warmup):
+                    sb.run(timed=False)
+                sb.sync()
+                for _ in range(args.steps):
+                    sb.run(timed=True)
+                sb.sync()
+                si = sb.info()
+                times[mode] = (si.sum_score_kernel_ms / max(si.timed_runs, 1), sb.fetch(), si.postings)
+                sb.close()
+            assert all(a.tobytes() == b_.tobytes() for a, b_ in zip(times[False][1], times[True][1])), "pruned single-term results differ"
+            subset = {"queries": len(st_queries), "postings_per_query": times[True][2] / len(st_queries),
+                      "kernel_ms_exhaustive": times[False][0], "kernel_ms_pruned": times[True][0]}
+            eng.use_pruning(True)
         pruned_leg = {
             "what": "same batch, kernel only; single-term queries (found = the list's posting count) skip the 256-posting blocks whose maximum cannot enter their top-K; all other queries exhaustive",
             "kernel_ms": k3, "queries_per_s_kernel": Qr / (k3 * 1e-3) if k3 > 0 else 0.0,
-            "single_term_queries": single, "build_s": build_s, "identical_results": same,
+            "single_term_queries": single, "single_term_queries_alone": subset, "build_s": build_s, "identical_results": same,
             "note": "not a roofline number: the bytes of skipped blocks are never read",
         }
         b3.close()

@@ -164,6 +164,7 @@ struct ns_ctx {
     // NS_ORDER_MODE (0 = off) / NS_ORDER_COARSE (log2 of the fine buckets per class) override it for experiments; read at
     // ns_ctx_create.
     int order_mode = 1, order_coarse = 3;
+    bool order_coarse_forced = false;   // NS_ORDER_COARSE given: no automatic choice
 };
 
 static thread_local std::string g_create_err;
@@ -279,7 +280,7 @@ extern "C" int ns_ctx_create(int device, ns_ctx** out) {
     ctx->stream = ctx->own_stream;
     if (const char* om = std::getenv("NS_ORDER_MODE")) ctx->order_mode = std::atoi(om);
     if (const char* um = std::getenv("NS_MERGE")) ctx->use_merge = std::atoi(um) != 0;
-    if (const char* oc = std::getenv("NS_ORDER_COARSE")) ctx->order_coarse = std::max(0, std::min(11, std::atoi(oc)));
+    if (const char* oc = std::getenv("NS_ORDER_COARSE")) { ctx->order_coarse = std::max(0, std::min(11, std::atoi(oc))); ctx->order_coarse_forced = true; }
     if (hipStreamCreateWithFlags(&ctx->alt_stream, hipStreamNonBlocking) != hipSuccess) { ctx->alt_stream = nullptr; (void)hipGetLastError(); }
     {
         int lo_pri = 0, hi_pri = 0;
@@ -1638,7 +1639,12 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
         // The classes are spread over the prepare threads; a class of n items costs one sort of n 64-bit words.
         if (deal) {
             DevWItem* wd = (DevWItem*)(hb + o_witems);
-            const uint32_t shift = (uint32_t)ctx->order_coarse;
+            // classes of 8 fine buckets while the index fits the 256 MiB Infinity Cache (an L2 miss is cheap there and the
+            // longest-first order matters more), of 16 when it does not (20 x 1M docs: L2-miss traffic 31.6 -> 28.6 GB at
+            // the same launch time; the 1M-doc index loses 3 % with 32, profiles/r03)
+            uint64_t resident = 0;
+            for (const ns_seg* sg_ : ctx->segs) if (sg_) resident += sg_->n_postings * 12ull;
+            const uint32_t shift = ctx->order_coarse_forced ? (uint32_t)ctx->order_coarse : (resident > (256ull << 20) ? 4u : 3u);
             const uint32_t n_cls = kOrderBuckets >> shift;
             if (P.deal_tmp.size() < width) { P.deal_tmp.resize(width); P.deal_key.resize(width); }
             fork([&](unsigned si) {
@@ -2007,10 +2013,11 @@ static int invert_run(ns_ctx* ctx, const uint32_t* doc_term_counts, uint32_t n_d
     hipStream_t st = ctx->stream;
     const uint32_t n = (uint32_t)n_pairs;
     const uint32_t n_tiles = (n + kIvTile - 1) / kIvTile;
-    // Digit plan, from n_terms alone (no device -> host sync decides it): the largest key is n_terms itself (the pairs the
-    // reference drops, src/lexicon.cpp:69-70); `bits` bits in ceil(bits / 11) passes of 8 .. 11 bits, as even as possible.
+    // Digit plan, from n_terms alone (no device -> host sync decides it): the keys are the termIds below n_terms — a pair with
+    // any other termId is dropped by the reference (src/lexicon.cpp:69-70) and leaves the sort in the first pass — so
+    // `bits` = the width of n_terms - 1, sorted in ceil(bits / 11) passes of 8 .. 11 bits, as even as possible.
     int bits = 1;
-    while (bits < 32 && (n_terms >> bits) != 0) bits++;
+    while (bits < 32 && n_terms > 1 && ((n_terms - 1) >> bits) != 0) bits++;
     const int passes = std::max(1, (bits + 10) / 11);
     int pbits[3] = {8, 8, 8};
     {
@@ -2018,8 +2025,7 @@ static int invert_run(ns_ctx* ctx, const uint32_t* doc_term_counts, uint32_t n_d
         for (int p = 0; p < passes; p++) {
             const int share = (left + (passes - p) - 1) / (passes - p);
             pbits[p] = std::min(11, std::max(8, share));
-            left -= pbits[p];
-            if (left < 0) left = 0;
+            left = std::max(0, left - pbits[p]);
         }
     }
     size_t m_max = 0;
@@ -2029,24 +2035,40 @@ static int invert_run(ns_ctx* ctx, const uint32_t* doc_term_counts, uint32_t n_d
     // one block from the ctx pool for all scratch arrays (a build loop inverts segment after segment of similar size;
     // ten hipMalloc + hipFree per call cost more than the device work)
     uint2 *d_pairs = nullptr, *d_vals[2] = {nullptr, nullptr};
-    uint32_t *d_keys[2] = {nullptr, nullptr}, *d_df = nullptr, *d_hist = nullptr, *d_sums = nullptr;
+    uint32_t *d_keys[2] = {nullptr, nullptr}, *d_df = nullptr, *d_first = nullptr, *d_hist = nullptr, *d_sums = nullptr, *d_kept = nullptr;
     uint64_t* d_prefix = nullptr;
+    uint2* d_tile_docs = nullptr;
+    // the documents that hold each tile's first and last pair (the host has the prefix sums; the first pass marks the
+    // documents that start in between): the last d with prefix[d] <= i
+    std::vector<uint32_t> tile_docs((size_t)n_tiles * 2);
+    {
+        uint32_t d = 0;
+        auto doc_of = [&](uint64_t i) { while (d + 1 < n_docs && prefix[d + 1] <= i) d++; return d; };   // i ascends: one sweep over the documents
+        for (uint32_t t = 0; t < n_tiles; t++) {
+            const uint64_t i0 = (uint64_t)t * kIvTile, i1 = std::min<uint64_t>(i0 + kIvTile, n) - 1;
+            tile_docs[2 * (size_t)t] = doc_of(i0);
+            tile_docs[2 * (size_t)t + 1] = doc_of(i1);
+        }
+    }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipError_t e = hipSuccess;
     auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
     size_t off = 0;
     auto place = [&](size_t bytes) { const size_t o = off; off = (off + std::max<size_t>(bytes, 1) + 255) & ~(size_t)255; return o; };
+    const size_t nt1 = (size_t)std::max<uint32_t>(n_terms, 1);
     const size_t o_pairs = place((size_t)n * 8), o_v0 = place((size_t)n * 8), o_v1 = place(passes > 1 ? (size_t)n * 8 : 1);
-    const size_t o_k0 = place(passes > 1 ? (size_t)n * 4 : 1), o_k1 = place(passes > 2 ? (size_t)n * 4 : 1);
-    const size_t o_df = place(((size_t)n_terms + 1) * 4), o_hist = place(m_max * 4), o_sums = place((size_t)scan_blocks_max * 4), o_prefix = place(prefix.size() * 8);
+    const size_t o_k0 = place((size_t)n * 4), o_k1 = place(passes > 1 ? (size_t)n * 4 : 1);
+    const size_t o_df = place(nt1 * 4), o_first = place(nt1 * 4), o_hist = place(m_max * 4), o_sums = place((size_t)scan_blocks_max * 4), o_kept = place(4), o_prefix = place(prefix.size() * 8), o_tdocs = place((size_t)n_tiles * 8);
     const size_t block_bytes = off;
     char* blk = nullptr;
     chk(pool_alloc(ctx, (void**)&blk, block_bytes));
     if (e == hipSuccess) {
         d_pairs = (uint2*)(blk + o_pairs); d_vals[0] = (uint2*)(blk + o_v0); d_vals[1] = (uint2*)(blk + o_v1);
         d_keys[0] = (uint32_t*)(blk + o_k0); d_keys[1] = (uint32_t*)(blk + o_k1);
-        d_df = (uint32_t*)(blk + o_df); d_hist = (uint32_t*)(blk + o_hist); d_sums = (uint32_t*)(blk + o_sums);
+        d_df = (uint32_t*)(blk + o_df); d_first = (uint32_t*)(blk + o_first); d_hist = (uint32_t*)(blk + o_hist); d_sums = (uint32_t*)(blk + o_sums);
+        d_kept = (uint32_t*)(blk + o_kept);
         d_prefix = (uint64_t*)(blk + o_prefix);
+        d_tile_docs = (uint2*)(blk + o_tdocs);
     }
     chk(hipEventCreate(&ev0));
     chk(hipEventCreate(&ev1));
@@ -2054,9 +2076,12 @@ static int invert_run(ns_ctx* ctx, const uint32_t* doc_term_counts, uint32_t n_d
     if (e == hipSuccess) {
         chk(hipMemcpyAsync(d_pairs, pairs, (size_t)n * 8, hipMemcpyHostToDevice, st));
         chk(hipMemcpyAsync(d_prefix, prefix.data(), prefix.size() * 8, hipMemcpyHostToDevice, st));
-        chk(hipMemsetAsync(d_df, 0, ((size_t)n_terms + 1) * 4, st));
+        chk(hipMemcpyAsync(d_tile_docs, tile_docs.data(), tile_docs.size() * 4, hipMemcpyHostToDevice, st));
+        chk(hipMemsetAsync(d_df, 0, nt1 * 4, st));
+        chk(hipMemsetAsync(d_first, 0xFF, nt1 * 4, st));
         chk(hipEventRecord(ev0, st));
-        // pass p reads (p == 0: the pairs; else keys / vals buffer `cur`) and writes buffer `nxt`; the last pass writes vals only
+        // pass p reads (p == 0: the pairs; else keys / vals buffer `cur`) and writes buffer `nxt`.  The number of items that
+        // survive the first pass (the kept pairs) stays on the device: the first scan leaves it in d_kept, later kernels read it.
         int cur = -1;
         uint32_t shift = 0;
         for (int p = 0; p < passes; p++) {
@@ -2066,10 +2091,9 @@ static int invert_run(ns_ctx* ctx, const uint32_t* doc_term_counts, uint32_t n_d
             const uint32_t scan_blocks = (uint32_t)((m + 1023) / 1024);
             const uint32_t* kin = first ? nullptr : d_keys[cur];
             const uint2* vin = first ? nullptr : d_vals[cur];
-            uint2* vout = d_vals[nxt];
-            uint32_t* kout = last ? nullptr : d_keys[nxt];
-#define NS_IV_HIST(B) hipLaunchKernelGGL((k_iv_hist_w<B>), dim3(n_tiles), dim3(256), 0, st, kin, first ? d_pairs : (const uint2*)nullptr, n, n_terms, shift, d_hist, n_tiles)
-#define NS_IV_PASS3(B, F, L) hipLaunchKernelGGL((k_iv_pass<B, F, L>), dim3(n_tiles), dim3(256), 0, st, d_pairs, d_prefix, n_docs, n_terms, kin, vin, kout, vout, n, shift, d_hist, n_tiles, d_df)
+            const uint32_t* n_dev = first ? nullptr : d_kept;
+#define NS_IV_HIST(B) hipLaunchKernelGGL((k_iv_hist_w<B>), dim3(n_tiles), dim3(256), 0, st, kin, first ? d_pairs : (const uint2*)nullptr, n, n_dev, n_terms, shift, d_hist, n_tiles)
+#define NS_IV_PASS3(B, F, L) hipLaunchKernelGGL((k_iv_pass<B, F, L>), dim3(n_tiles), dim3(256), 0, st, d_pairs, d_prefix, d_tile_docs, n_terms, kin, vin, d_keys[nxt], d_vals[nxt], n, n_dev, shift, d_hist, n_tiles)
 #define NS_IV_PASS(B) { if (first && last) NS_IV_PASS3(B, true, true); else if (first) NS_IV_PASS3(B, true, false); else if (last) NS_IV_PASS3(B, false, true); else NS_IV_PASS3(B, false, false); }
             switch (pbits[p]) {
                 case 8: NS_IV_HIST(8); break;
@@ -2078,7 +2102,7 @@ static int invert_run(ns_ctx* ctx, const uint32_t* doc_term_counts, uint32_t n_d
                 default: NS_IV_HIST(11); break;
             }
             hipLaunchKernelGGL(k_iv_scan_sums, dim3(scan_blocks), dim3(256), 0, st, d_hist, (uint32_t)m, d_sums);
-            hipLaunchKernelGGL(k_iv_scan_top, dim3(1), dim3(1024), 0, st, d_sums, scan_blocks);
+            hipLaunchKernelGGL(k_iv_scan_top, dim3(1), dim3(1024), 0, st, d_sums, scan_blocks, first ? d_kept : (uint32_t*)nullptr);
             hipLaunchKernelGGL(k_iv_scan_apply, dim3(scan_blocks), dim3(256), 0, st, d_hist, (uint32_t)m, d_sums);
             switch (pbits[p]) {
                 case 8: NS_IV_PASS(8); break;
@@ -2093,14 +2117,19 @@ static int invert_run(ns_ctx* ctx, const uint32_t* doc_term_counts, uint32_t n_d
             cur = nxt;
         }
         d_final = d_vals[cur];
+        // df from the sorted keys: a run's first pair records where it starts, its last pair where it ends (d_df holds the ends)
+        if (n_terms) hipLaunchKernelGGL(k_iv_runs, dim3((n + 1023) / 1024), dim3(256), 0, st, d_keys[cur], n, n_terms, d_first, d_df, d_kept);
         chk(hipEventRecord(ev1, st));
         chk(hipGetLastError());
+        std::vector<uint32_t> h_first(n_terms);
         if (n_terms) chk(hipMemcpyAsync(df_out, d_df, (size_t)n_terms * 4, hipMemcpyDeviceToHost, st));
+        if (n_terms) chk(hipMemcpyAsync(h_first.data(), d_first, (size_t)n_terms * 4, hipMemcpyDeviceToHost, st));
         chk(hipStreamSynchronize(st));
         if (e == hipSuccess) {
             uint64_t kept = 0;
+            for (uint32_t t = 0; t < n_terms; t++) df_out[t] = (h_first[t] == 0xFFFFFFFFu) ? 0u : df_out[t] - h_first[t] + 1u;
             for (uint32_t t = 0; t < n_terms; t++) kept += df_out[t];
-            *kept_out = kept;   // the dropped pairs carry the largest key: they sort behind every list and are not written
+            *kept_out = kept;   // the dropped pairs left the sort in the first pass
             if (kept && postings_out) chk(hipMemcpy(postings_out, d_final, (size_t)kept * 8, hipMemcpyDeviceToHost));
             if (adopt) {   // the lists stay on the device: they ARE the segment's posting stream
                 if (kept) chk(hipMemcpyAsync(adopt->d_postings, d_final, (size_t)kept * 8, hipMemcpyDeviceToDevice, st));

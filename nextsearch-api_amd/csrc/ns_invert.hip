@@ -4,21 +4,21 @@
 // (termId, tf) of every document to a per-term std::vector and std::sorts each vector by docId.
 //
 // Here: forward.bin lists documents in docId order, so a STABLE sort of the (termId, tf) pairs by termId
-// alone yields every list already sorted by docId.  That is an LSD radix sort with 8-bit digits over
-// ceil(log2(n_terms + 1) / 8) passes (2 for a 65 536-term vocabulary, 3 up to 16 M terms):
+// alone yields every list already sorted by docId.  That is an LSD radix sort over the bits of n_terms - 1 in
+// ceil(bits / 11) passes of 8 .. 11 bits (2 passes for every vocabulary up to 4 M terms):
 //
-//   k_iv_expand   pair i -> key = termId (n_terms for the ids the reference drops, :70), value = {docId, tf};
-//                 docIds from the prefix sums of the per-document counts (boundaries marked per tile in LDS);
-//                 counts the dropped pairs: without any, the keys need one bit less (often one pass less)
-//   per pass:     k_iv_hist (LDS histogram per 4096-pair tile, written digit-major) -> exclusive scan of the
-//                 256 x tiles counters -> k_iv_scatter (stable ranks: wave-level match masks from 8 ballots,
-//                 per-wave digit counters in LDS, waves of a tile ordered by a 256-thread prefix)
+//   per pass:     k_iv_hist_w (LDS histogram per 4096-item tile, written digit-major; the first pass reads the pairs
+//                 themselves) -> exclusive scan of the BINS x tiles counters -> k_iv_pass (stable ranks: wave-level match
+//                 masks from ballots, per-wave digit counters in LDS, the tile put in digit order in LDS before it leaves)
+//   first pass:   makes the docIds on the way (prefix sums of the per-document counts, boundaries marked per tile in LDS)
+//                 and lets the pairs the reference drops (:69-70) fall out: they are neither ranked nor written
 //   k_iv_runs     first / last position of every term's run in the sorted keys (df = last - first + 1)
 //
 // Integer work only; the result is defined bit for bit (the one freedom the reference leaves — the order of
 // equal docIds inside a list, std::sort being unstable — is resolved as input order).
-// Algorithmic bytes per pair: 8 B read (termId, tf) + 8 B written (docId, tf) = 16 B; the radix passes move
-// 12 B in + 12 B out per pair per pass plus 4 B for the histogram read.
+// Algorithmic bytes per pair: 8 B read (termId, tf) + 8 B written (docId, tf) = 16 B.  Moved, two passes: 8 (histogram
+// over the pairs) + 8 + 12 (first pass) + 4 (histogram over the keys) + 12 + 12 (second pass) + 4 (runs) + the digit
+// counters = ~62 B; round 2's expand + two or three 8-bit passes moved 80 or 108 B.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -28,114 +28,31 @@ namespace ns {
 constexpr int kIvItems = 16;                 // pairs per thread per tile
 constexpr int kIvTile = 256 * kIvItems;      // pairs per workgroup
 
-// One workgroup per tile of 4096 pairs.  The documents that START inside the tile mark their first pair in
-// LDS (an empty document shares its position with the next one: the largest docId wins, as the pair belongs
-// to the last document that starts at or before it); a running maximum then gives every pair its docId.
-// Two binary searches per tile (its first and last pair) instead of one per pair.
-__global__ void __launch_bounds__(256) k_iv_expand(const uint2* __restrict__ pairs, const uint64_t* __restrict__ doc_prefix,
-                                                   uint32_t n_docs, uint32_t n_pairs, uint32_t n_terms,
-                                                   uint32_t* __restrict__ keys, uint2* __restrict__ vals, uint32_t* __restrict__ n_dropped) {
-    __shared__ uint32_t s_doc[kIvTile];
-    __shared__ uint32_t s_ends[2];
-    __shared__ uint32_t s_wmax[4];
-    __shared__ uint32_t s_drop;
-    const uint32_t tile0 = blockIdx.x * (uint32_t)kIvTile;
-    const uint32_t count = min((uint32_t)kIvTile, n_pairs - tile0);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-    for (int s = 0; s < kIvItems; s++) s_doc[s * 256 + threadIdx.x] = 0;
-    if (threadIdx.x == 0) s_drop = 0;
-    if (threadIdx.x < 2) {   // the document that holds pair i: the last d with doc_prefix[d] <= i
-        const uint64_t i = (uint64_t)tile0 + (threadIdx.x ? count - 1 : 0u);
-        uint32_t lo = 0, hi = n_docs;
-        while (lo < hi) {
-            const uint32_t mid = lo + ((hi - lo) >> 1);
-            if (doc_prefix[mid + 1] <= i) lo = mid + 1; else hi = mid;
-        }
-        s_ends[threadIdx.x] = lo;
-    }
-    __syncthreads();
-    const uint32_t d0 = s_ends[0], d1 = s_ends[1];
-    if (threadIdx.x == 0) s_doc[0] = d0;
-    for (uint32_t d = d0 + 1 + threadIdx.x; d <= d1; d += 256) atomicMax(&s_doc[(uint32_t)(doc_prefix[d] - tile0)], d);
-    __syncthreads();
-    // running maximum: thread t owns positions [16t, 16t + 16)
-    uint32_t m[kIvItems], run = 0;
-#pragma unroll
-    for (int j = 0; j < kIvItems; j++) { run = max(run, s_doc[threadIdx.x * kIvItems + j]); m[j] = run; }
-    uint32_t inc = run;
-#pragma unroll
-    for (int dd = 1; dd < 64; dd <<= 1) {
-        const uint32_t o = __shfl_up(inc, dd, 64);
-        if (lane >= dd) inc = max(inc, o);
-    }
-    if (lane == 63) s_wmax[w] = inc;
-    const uint32_t before_lane = __shfl_up(inc, 1, 64);
-    __syncthreads();
-    uint32_t before = lane ? before_lane : 0u;
-    for (int j = 0; j < w; j++) before = max(before, s_wmax[j]);
-#pragma unroll
-    for (int j = 0; j < kIvItems; j++) s_doc[threadIdx.x * kIvItems + j] = max(m[j], before);
-    __syncthreads();
-    uint32_t dropped = 0;
-#pragma unroll
-    for (int s = 0; s < kIvItems; s++) {
-        const uint32_t li = (uint32_t)s * 256 + threadIdx.x;
-        if (li < count) {
-            const uint2 p = pairs[tile0 + li];   // {termId, tf}
-            const bool keep = p.x < n_terms;
-            dropped += keep ? 0u : 1u;
-            keys[tile0 + li] = keep ? p.x : n_terms;
-            vals[tile0 + li] = make_uint2(s_doc[li], p.y);
-        }
-    }
-    if (dropped) atomicAdd(&s_drop, dropped);
-    __syncthreads();
-    if (threadIdx.x == 0 && s_drop) atomicAdd(n_dropped, s_drop);
-}
-
 // df from the SORTED keys (a histogram by atomics serialises on the frequent terms: the most frequent one
 // occurs in almost every document): a run's first pair records where it starts, its last pair where it ends;
 // the host subtracts.
-__global__ void __launch_bounds__(256) k_iv_runs(const uint32_t* __restrict__ keys, uint32_t n, uint32_t n_terms,
-                                                 uint32_t* __restrict__ first, uint32_t* __restrict__ last) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t k = keys[i];
-    if (k >= n_terms) return;
-    if (i == 0 || keys[i - 1] != k) first[k] = i;
-    if (i + 1 == n || keys[i + 1] != k) last[k] = i;
-}
-
-// Each thread counts 16 CONSECUTIVE keys and issues one LDS atomic per run of equal digits: with 64 lanes adding
-// to the same counter an LDS atomic serialises, and in the upper-byte passes (Zipf-distributed termIds) almost every
-// key of a tile has the same digit.
-__global__ void __launch_bounds__(256) k_iv_hist(const uint32_t* __restrict__ keys, uint32_t n, uint32_t shift,
-                                                 uint32_t* __restrict__ tile_hist /* [256][n_tiles] */, uint32_t n_tiles) {
-    __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t base = blockIdx.x * (uint32_t)kIvTile + threadIdx.x * (uint32_t)kIvItems;
-    if (base + kIvItems <= n) {
-        const uint4* p = reinterpret_cast<const uint4*>(keys + base);   // base is a multiple of 16 keys = 64 B
-        uint32_t k[kIvItems];
-#pragma unroll
-        for (int j = 0; j < kIvItems / 4; j++) {
-            const uint4 v = p[j];
-            k[4 * j] = v.x; k[4 * j + 1] = v.y; k[4 * j + 2] = v.z; k[4 * j + 3] = v.w;
-        }
-        uint32_t d = (k[0] >> shift) & 255u, run = 1;
-#pragma unroll
-        for (int j = 1; j < kIvItems; j++) {
-            const uint32_t dj = (k[j] >> shift) & 255u;
-            if (dj == d) { run++; } else { atomicAdd(&h[d], run); d = dj; run = 1; }
-        }
-        atomicAdd(&h[d], run);
+__global__ void __launch_bounds__(256) k_iv_runs(const uint32_t* __restrict__ keys, uint32_t n_arg, uint32_t n_terms,
+                                                 uint32_t* __restrict__ first, uint32_t* __restrict__ last, const uint32_t* __restrict__ n_dev = nullptr) {
+    const uint32_t n = n_dev ? *n_dev : n_arg;
+    const uint32_t i0 = (blockIdx.x * 256 + threadIdx.x) * 4u;   // four consecutive keys per thread: one 16-byte load + the two neighbours
+    if (i0 >= n) return;
+    uint32_t k[6];
+    k[0] = i0 ? keys[i0 - 1] : 0xFFFFFFFFu;
+    if (i0 + 4 <= n) {
+        const uint4 v = *reinterpret_cast<const uint4*>(keys + i0);
+        k[1] = v.x; k[2] = v.y; k[3] = v.z; k[4] = v.w;
     } else {
-        for (uint32_t i = base; i < n && i < base + kIvItems; i++) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+#pragma unroll
+        for (int j = 0; j < 4; j++) k[1 + j] = i0 + (uint32_t)j < n ? keys[i0 + j] : 0xFFFFFFFFu;
     }
-    __syncthreads();
-    tile_hist[(size_t)threadIdx.x * n_tiles + blockIdx.x] = h[threadIdx.x];
+    k[5] = i0 + 4 < n ? keys[i0 + 4] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t i = i0 + (uint32_t)j;
+        if (i >= n || k[1 + j] >= n_terms) continue;
+        if (i == 0 || k[j] != k[1 + j]) first[k[1 + j]] = i;
+        if (i + 1 == n || k[2 + j] != k[1 + j]) last[k[1 + j]] = i;
+    }
 }
 
 // ---- exclusive scan of a flat u32 array (three small kernels; 1024 elements per workgroup) ----
@@ -154,7 +71,7 @@ __global__ void __launch_bounds__(256) k_iv_scan_sums(const uint32_t* __restrict
     __syncthreads();
     if (threadIdx.x == 0) sums[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
-__global__ void __launch_bounds__(1024) k_iv_scan_top(uint32_t* __restrict__ sums, uint32_t n) {   // one workgroup, in place, exclusive
+__global__ void __launch_bounds__(1024) k_iv_scan_top(uint32_t* __restrict__ sums, uint32_t n, uint32_t* __restrict__ total_out = nullptr) {   // one workgroup, in place, exclusive; total_out (optional): the sum of all
     __shared__ uint32_t part[1024];
     __shared__ uint32_t carry;
     if (threadIdx.x == 0) carry = 0;
@@ -176,6 +93,7 @@ __global__ void __launch_bounds__(1024) k_iv_scan_top(uint32_t* __restrict__ sum
         if (threadIdx.x == 1023) carry = c + part[1023];
         __syncthreads();
     }
+    if (total_out && threadIdx.x == 0) *total_out = carry;
 }
 __global__ void __launch_bounds__(256) k_iv_scan_apply(uint32_t* __restrict__ a, uint32_t m, const uint32_t* __restrict__ sums) {
     __shared__ uint32_t wsum[4];
@@ -207,125 +125,49 @@ __global__ void __launch_bounds__(256) k_iv_scan_apply(uint32_t* __restrict__ a,
     }
 }
 
-// Stable scatter of one tile.  Wave w owns the tile's pairs [w*1024, (w+1)*1024) in 16 steps of 64; inside a
-// step the pairs with the same digit find each other with 8 ballots; ranks continue from the wave's running
-// per-digit counter in LDS (LDS operations of one wave execute in order).  The tile is then put in digit
-// order IN LDS and leaves from there: consecutive lanes write consecutive addresses of a (tile, digit) run
-// (written straight from the ranks, every lane of a store hit a different run: 12-B writes scattered 256 ways).
-__global__ void __launch_bounds__(256) k_iv_scatter(const uint32_t* __restrict__ keys_in, const uint2* __restrict__ vals_in,
-                                                    uint32_t* __restrict__ keys_out, uint2* __restrict__ vals_out, uint32_t n,
-                                                    uint32_t shift, const uint32_t* __restrict__ tile_base /* scanned [256][n_tiles] */,
-                                                    uint32_t n_tiles) {
-    __shared__ uint32_t wcnt[4][256];
-    __shared__ uint32_t gdelta[256];     // where digit d's run of this tile starts in the output, minus its start in the tile
-    __shared__ uint32_t wtot[4];
-    __shared__ uint32_t s_key[kIvTile];
-    __shared__ uint2 s_val[kIvTile];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll
-    for (int j = 0; j < 4; j++) wcnt[j][threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t tile0 = blockIdx.x * (uint32_t)kIvTile;
-    const uint32_t base = tile0 + (uint32_t)w * (64u * kIvItems);
-    const uint64_t lt = (1ull << lane) - 1ull;
-    uint32_t key[kIvItems], rank[kIvItems];
-    uint2 val[kIvItems];
-#pragma unroll
-    for (int s = 0; s < kIvItems; s++) {
-        const uint32_t idx = base + (uint32_t)s * 64 + (uint32_t)lane;
-        const bool valid = idx < n;
-        key[s] = valid ? keys_in[idx] : 0xFFFFFFFFu;
-        val[s] = valid ? vals_in[idx] : make_uint2(0u, 0u);
-    }
-#pragma unroll
-    for (int s = 0; s < kIvItems; s++) {
-        const uint32_t idx = base + (uint32_t)s * 64 + (uint32_t)lane;
-        const bool valid = idx < n;
-        const uint32_t d = (key[s] >> shift) & 255u;
-        uint64_t mask = __builtin_amdgcn_ballot_w64(valid);
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            const bool bit = (d >> b) & 1u;
-            const uint64_t bal = __builtin_amdgcn_ballot_w64(bit);
-            mask &= bit ? bal : ~bal;
-        }
-        const uint32_t prev = wcnt[w][d];
-        rank[s] = prev + (uint32_t)__popcll(mask & lt);
-        if (valid && (mask & lt) == 0ull) wcnt[w][d] = prev + (uint32_t)__popcll(mask);   // the group's first lane
-    }
-    __syncthreads();
-    {   // thread d: digit d's start in the tile (exclusive scan of the digit totals), the waves' starts inside it
-        const uint32_t d = threadIdx.x;
-        uint32_t c[4], tot = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) { c[j] = wcnt[j][d]; tot += c[j]; }
-        uint32_t inc = tot;
-#pragma unroll
-        for (int dd = 1; dd < 64; dd <<= 1) {
-            const uint32_t o = __shfl_up(inc, dd, 64);
-            if (lane >= dd) inc += o;
-        }
-        if (lane == 63) wtot[w] = inc;
-        __syncthreads();
-        uint32_t ex = inc - tot;
-        for (int j = 0; j < w; j++) ex += wtot[j];
-        gdelta[d] = tile_base[(size_t)d * n_tiles + blockIdx.x] - ex;
-        uint32_t run = ex;
-#pragma unroll
-        for (int j = 0; j < 4; j++) { wcnt[j][d] = run; run += c[j]; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < kIvItems; s++) {
-        const uint32_t idx = base + (uint32_t)s * 64 + (uint32_t)lane;
-        if (idx < n) {
-            const uint32_t lp = wcnt[w][(key[s] >> shift) & 255u] + rank[s];
-            s_key[lp] = key[s];
-            s_val[lp] = val[s];
-        }
-    }
-    __syncthreads();
-    const uint32_t count = min((uint32_t)kIvTile, n - tile0);
-#pragma unroll
-    for (int s = 0; s < kIvItems; s++) {
-        const uint32_t i = (uint32_t)s * 256 + threadIdx.x;
-        if (i < count) {
-            const uint32_t k = s_key[i];
-            const uint32_t pos = gdelta[(k >> shift) & 255u] + i;
-            keys_out[pos] = k;
-            vals_out[pos] = s_val[i];
-        }
-    }
-}
 
-
-// ================================================================================================================
-// Round 3: the passes WITHOUT the expand pass, without a key array in the last pass, and with digits as wide as the key needs
-// (the judge's round-2 item: ~100 B moved per 16 B algorithmic pair).
-//   * digit widths: a key of `bits` bits (the largest key is n_terms itself: the pairs the reference drops, :69-70) is
-//     sorted in ceil(bits / 11) passes of 8 .. 11 bits each — 2 passes for every vocabulary up to 4 M terms, decided from
-//     n_terms alone (round 2 needed a device -> host sync on the number of dropped pairs to choose between 2 and 3);
-//   * the FIRST pass reads forward.bin's {termId, tf} pairs directly and makes the docIds on the way (the expand kernel's
-//     boundary marks, in the LDS the tile is staged in later): no {key, docId, tf} copy is written and read back;
-//   * the LAST pass writes {docId, tf} only, and counts df from the tile once it stands in digit order in LDS: equal keys
-//     are neighbours there (the input is sorted by the lower digits and the partition is stable), one atomicAdd per run.
-// Bytes per pair, two passes: 8 (histogram over the pairs) + 8 + 12 (first pass) + 4 (histogram over the keys) + 12 + 8
-// (last pass) + ~2 x 1 (per-tile digit counters) = ~54, against 80 (2 passes) / 108 (3 passes, whenever a pair was dropped).
+// ---- the passes (round 3: no separate expand pass, digits as wide as the keys need, dropped pairs out in the first pass;
+//      the pass count follows from n_terms alone — round 2 needed a device -> host sync on the number of dropped pairs
+//      to choose between 2 and 3 passes.  Counting df with one atomicAdd per run of equal keys of a tile in the last pass
+//      was built and measured: 10 M atomics, 2.8 ms — the sorted keys and k_iv_runs stay) ----
 
 template <int BITS>
-__global__ void __launch_bounds__(256) k_iv_hist_w(const uint32_t* __restrict__ keys, const uint2* __restrict__ pairs, uint32_t n,
+__global__ void __launch_bounds__(256) k_iv_hist_w(const uint32_t* __restrict__ keys, const uint2* __restrict__ pairs, uint32_t n_arg,
+                                                    const uint32_t* __restrict__ n_dev /* number of items, when only the device knows it */,
                                                     uint32_t n_terms, uint32_t shift, uint32_t* __restrict__ tile_hist /* [BINS][n_tiles] */,
                                                     uint32_t n_tiles) {
     constexpr int BINS = 1 << BITS;
     __shared__ uint32_t h[BINS];
+    const uint32_t n = n_dev ? *n_dev : n_arg;
     for (int d = threadIdx.x; d < BINS; d += 256) h[d] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * (uint32_t)kIvTile + threadIdx.x * (uint32_t)kIvItems;
-    uint32_t d = 0xFFFFFFFFu, run = 0;   // one LDS atomic per run of equal digits among the thread's 16 consecutive keys
-    for (uint32_t i = base; i < n && i < base + kIvItems; i++) {
-        uint32_t k;
-        if (pairs) { const uint32_t t = pairs[i].x; k = t < n_terms ? t : n_terms; } else k = keys[i];
-        const uint32_t dj = (k >> shift) & (uint32_t)(BINS - 1);
+    // the thread's 16 consecutive keys (a pair's key is its termId; a termId the reference drops, src/lexicon.cpp:69-70, is
+    // not counted: such a pair leaves the sort in the first pass); 16-byte loads (base is a multiple of 16 items)
+    uint32_t k[kIvItems];
+    if (base + kIvItems <= n) {
+        if (pairs) {
+            const uint4* p = reinterpret_cast<const uint4*>(pairs + base);
+#pragma unroll
+            for (int j = 0; j < kIvItems / 2; j++) { const uint4 v = p[j]; k[2 * j] = v.x; k[2 * j + 1] = v.z; }
+        } else {
+            const uint4* p = reinterpret_cast<const uint4*>(keys + base);
+#pragma unroll
+            for (int j = 0; j < kIvItems / 4; j++) { const uint4 v = p[j]; k[4 * j] = v.x; k[4 * j + 1] = v.y; k[4 * j + 2] = v.z; k[4 * j + 3] = v.w; }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kIvItems; j++) {
+            const uint32_t i = base + (uint32_t)j;
+            k[j] = i < n ? (pairs ? pairs[i].x : keys[i]) : 0xFFFFFFFFu;
+        }
+    }
+    uint32_t d = 0xFFFFFFFFu, run = 0;   // one LDS atomic per run of equal digits among the thread's keys
+#pragma unroll
+    for (int j = 0; j < kIvItems; j++) {
+        const bool counted = pairs ? k[j] < n_terms : (base + (uint32_t)j < n);
+        if (!counted) continue;
+        const uint32_t dj = (k[j] >> shift) & (uint32_t)(BINS - 1);
         if (dj == d) { run++; } else { if (run) atomicAdd(&h[d], run); d = dj; run = 1; }
     }
     if (run) atomicAdd(&h[d], run);
@@ -334,43 +176,39 @@ __global__ void __launch_bounds__(256) k_iv_hist_w(const uint32_t* __restrict__ 
 }
 
 // One pass over one tile: stable partition by the digit (key >> shift) & (BINS - 1).
-//   FIRST: the input is forward.bin's pairs (key = termId, or n_terms for the ids the reference drops; docIds made here)
-//   LAST : only {docId, tf} of the kept pairs leave, and df[key] is counted from the tile in digit order
+//   FIRST: the input is forward.bin's pairs (key = termId; a pair whose termId the reference drops, src/lexicon.cpp:69-70,
+//          takes no part: it is neither ranked nor written, so the keys need no extra bit for it; docIds are made here)
+// n_in = items of the input (pairs, or what the previous pass wrote); df comes from the sorted keys afterwards (k_iv_runs)
 template <int BITS, bool FIRST, bool LAST>
-__global__ void __launch_bounds__(256) k_iv_pass(const uint2* __restrict__ pairs, const uint64_t* __restrict__ doc_prefix, uint32_t n_docs,
+__global__ void __launch_bounds__(256) k_iv_pass(const uint2* __restrict__ pairs, const uint64_t* __restrict__ doc_prefix,
+                                                 const uint2* __restrict__ tile_docs /* FIRST: per tile {doc of its first pair, doc of its last pair} */,
                                                  uint32_t n_terms, const uint32_t* __restrict__ keys_in, const uint2* __restrict__ vals_in,
-                                                 uint32_t* __restrict__ keys_out, uint2* __restrict__ vals_out, uint32_t n, uint32_t shift,
-                                                 const uint32_t* __restrict__ tile_base /* scanned [BINS][n_tiles] */, uint32_t n_tiles,
-                                                 uint32_t* __restrict__ df /* [n_terms + 1] */) {
+                                                 uint32_t* __restrict__ keys_out, uint2* __restrict__ vals_out, uint32_t n_arg,
+                                                 const uint32_t* __restrict__ n_dev, uint32_t shift,
+                                                 const uint32_t* __restrict__ tile_base /* scanned [BINS][n_tiles] */, uint32_t n_tiles) {
     constexpr int BINS = 1 << BITS;
+    const uint32_t n = n_dev ? *n_dev : n_arg;
     constexpr int DPT = BINS / 256;              // digits per thread in the digit-start scan
     __shared__ uint32_t wcnt[4][BINS];
     __shared__ uint32_t gdelta[BINS];             // where digit d's run of this tile starts in the output, minus its start in the tile
     __shared__ uint32_t wtot[4];
     __shared__ uint32_t s_key[kIvTile];           // FIRST: the tile's docIds until the keys are staged here
     __shared__ uint2 s_val[kIvTile];
-    __shared__ uint32_t s_ends[2];
     __shared__ uint32_t s_wmax[4];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int d = threadIdx.x; d < 4 * BINS; d += 256) (&wcnt[0][0])[d] = 0;
     const uint32_t tile0 = blockIdx.x * (uint32_t)kIvTile;
-    const uint32_t count = min((uint32_t)kIvTile, n - tile0);
+    if (tile0 >= n) return;   // (a later pass is launched for the first pass's item count: the dropped pairs' tiles are empty)
     if (FIRST) {
         // docIds: the documents that START inside the tile mark their first pair; a running maximum gives every pair its doc
         uint32_t* s_doc = s_key;
 #pragma unroll
         for (int s = 0; s < kIvItems; s++) s_doc[s * 256 + threadIdx.x] = 0;
-        if (threadIdx.x < 2) {   // the document that holds pair i: the last d with doc_prefix[d] <= i
-            const uint64_t i = (uint64_t)tile0 + (threadIdx.x ? count - 1 : 0u);
-            uint32_t lo = 0, hi = n_docs;
-            while (lo < hi) {
-                const uint32_t mid = lo + ((hi - lo) >> 1);
-                if (doc_prefix[mid + 1] <= i) lo = mid + 1; else hi = mid;
-            }
-            s_ends[threadIdx.x] = lo;
-        }
-        __syncthreads();
-        const uint32_t d0 = s_ends[0], d1 = s_ends[1];
+        // (the documents of the tile's first and last pair come from the host, which holds the prefix sums: two binary
+        //  searches per tile on the device were two threads' chains of ~20 dependent loads in front of everything else)
+        const uint2 td = tile_docs[blockIdx.x];
+        const uint32_t d0 = td.x, d1 = td.y;
+        __syncthreads();   // the zeroes above are in place
         if (threadIdx.x == 0) s_doc[0] = d0;
         for (uint32_t d = d0 + 1 + threadIdx.x; d <= d1; d += 256) atomicMax(&s_doc[(uint32_t)(doc_prefix[d] - tile0)], d);
         __syncthreads();
@@ -402,7 +240,7 @@ __global__ void __launch_bounds__(256) k_iv_pass(const uint2* __restrict__ pairs
         const bool valid = idx < n;
         if (FIRST) {
             const uint2 p = valid ? pairs[idx] : make_uint2(0xFFFFFFFFu, 0u);
-            key[s] = valid ? (p.x < n_terms ? p.x : n_terms) : 0xFFFFFFFFu;
+            key[s] = (valid && p.x < n_terms) ? p.x : 0xFFFFFFFFu;   // ~0: not part of the sort (past the end, or a dropped termId)
             val[s] = make_uint2(valid ? s_key[idx - tile0] : 0u, p.y);
         } else {
             key[s] = valid ? keys_in[idx] : 0xFFFFFFFFu;
@@ -411,8 +249,7 @@ __global__ void __launch_bounds__(256) k_iv_pass(const uint2* __restrict__ pairs
     }
 #pragma unroll
     for (int s = 0; s < kIvItems; s++) {
-        const uint32_t idx = base + (uint32_t)s * 64 + (uint32_t)lane;
-        const bool valid = idx < n;
+        const bool valid = key[s] != 0xFFFFFFFFu;
         const uint32_t d = (key[s] >> shift) & (uint32_t)(BINS - 1);
         uint64_t mask = __builtin_amdgcn_ballot_w64(valid);
 #pragma unroll
@@ -458,36 +295,23 @@ __global__ void __launch_bounds__(256) k_iv_pass(const uint2* __restrict__ pairs
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < kIvItems; s++) {
-        const uint32_t idx = base + (uint32_t)s * 64 + (uint32_t)lane;
-        if (idx < n) {
+        if (key[s] != 0xFFFFFFFFu) {
             const uint32_t lp = wcnt[w][(key[s] >> shift) & (uint32_t)(BINS - 1)] + rank[s];
             s_key[lp] = key[s];
             s_val[lp] = val[s];
         }
     }
     __syncthreads();
+    const uint32_t staged = wtot[0] + wtot[1] + wtot[2] + wtot[3];   // the tile's items that take part (FIRST: without the dropped pairs)
 #pragma unroll
     for (int s = 0; s < kIvItems; s++) {
         const uint32_t i = (uint32_t)s * 256 + threadIdx.x;
-        if (i < count) {
+        if (i < staged) {
             const uint32_t k = s_key[i];
             const uint32_t pos = gdelta[(k >> shift) & (uint32_t)(BINS - 1)] + i;
-            if (LAST) {
-                if (k < n_terms) vals_out[pos] = s_val[i];   // the dropped pairs carry the largest key: they sort behind every list
-            } else {
-                keys_out[pos] = k;
-                vals_out[pos] = s_val[i];
-            }
+            keys_out[pos] = k;
+            vals_out[pos] = s_val[i];
         }
-    }
-    if (LAST) {   // df: the tile stands in digit order, equal keys are neighbours; thread t counts the runs among its 16 positions
-        const uint32_t i0 = threadIdx.x * (uint32_t)kIvItems;
-        uint32_t k = 0xFFFFFFFFu, run = 0;
-        for (uint32_t i = i0; i < count && i < i0 + kIvItems; i++) {
-            const uint32_t kj = s_key[i];
-            if (kj == k) { run++; } else { if (run) atomicAdd(&df[k], run); k = kj; run = 1; }
-        }
-        if (run) atomicAdd(&df[k], run);
     }
 }
 

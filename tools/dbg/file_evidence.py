@@ -3,7 +3,7 @@
     python3 tools/dbg/file_evidence.py <dir> <round e.g. r02>"""
 import collections, csv, glob, json, os, re, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-O = os.path.join(ROOT, "gpurun_out", sys.argv[1]); RND = sys.argv[2] if len(sys.argv) > 2 else "r02"
+O = os.path.join(ROOT, "gpurun_out", sys.argv[1]); RND = sys.argv[2] if len(sys.argv) > 2 else "r03"
 P = os.path.join(ROOT, "profiles", RND); os.makedirs(P, exist_ok=True)
 tj_path = os.path.join(ROOT, "profiles", "traffic.json")
 tj = json.load(open(tj_path))
@@ -25,7 +25,8 @@ if os.path.exists(f"{O}/stats/cfg5_kernel_stats.csv"):
     open(f"{P}/final_cfg5_kernel_trace_head.csv", "w").writelines(open(f"{O}/stats/cfg5_kernel_trace.csv").readlines()[:40])
     print(open(f"{P}/final_cfg5_kernel_stats.csv").read().split("\n")[1][:200])
 for a, b in (("law_bench.txt", "final_law_bench.txt"), ("law_big20.txt", "final_law_bench_big20.txt"), ("e2e.txt", "final_e2e_host_inclusive.txt"), ("tests.txt", "final_gpu_tests.txt"),
-             ("n2_strong.json", "final_n2_gloo_rehearsal_strong.json"), ("n2_weak.json", "final_n2_gloo_rehearsal_weak.json")):
+             ("n2_strong.json", "final_n2_gloo_rehearsal_strong.json"), ("n2_weak.json", "final_n2_gloo_rehearsal_weak.json"),
+             ("facade_bench.txt", "final_facade_bench.txt")):
     if os.path.exists(f"{O}/{a}"):
         shutil.copy(f"{O}/{a}", f"{P}/{b}")
 if os.path.exists(f"{O}/pmc_fetch/cfg5_counter_collection.csv"):
@@ -49,10 +50,28 @@ if os.path.exists(f"{O}/pmc_fetch/cfg5_counter_collection.csv"):
     print(f"VALU {m['SQ_INSTS_VALU']:.4g} SALU {m['SQ_INSTS_SALU']:.4g} LDS {m['SQ_INSTS_LDS']:.3g} VALU issue {m['SQ_ACTIVE_INST_VALU'] / cap:.2f} SALU issue {m['SQ_INSTS_SALU'] / cap:.2f} "
           f"waves avg {m['SQ_WAVE_CYCLES'] * 4 / cyc:.0f} wait_any {m['SQ_WAIT_ANY'] / m['SQ_WAVE_CYCLES']:.2f} wait_inst {m['SQ_WAIT_INST_ANY'] / m['SQ_WAVE_CYCLES']:.2f}")
     open(f"{P}/final_cfg5_pmc_sq.csv", "w").write("counter,mean_per_dispatch\n" + "\n".join(f"{k},{v:.6g}" for k, v in m.items()) + "\n")
+# the hbm_resident leg of bench.py alone (bench.py --hbm-only): kernel stats and L2-miss traffic of exactly that launch
+if os.path.exists(f"{O}/hbm_stats/hbm_leg_kernel_stats.csv"):
+    open(f"{P}/final_hbm_leg_kernel_stats.csv", "w").write(re.sub(r'\(ns::[^"]*\)"', '"', open(f"{O}/hbm_stats/hbm_leg_kernel_stats.csv").read()))
+    print("hbm leg:", open(f"{P}/final_hbm_leg_kernel_stats.csv").read().split("\n")[1][:200])
+    if os.path.exists(f"{O}/hbm_stats/hbm_leg.json") and os.path.getsize(f"{O}/hbm_stats/hbm_leg.json") > 10:
+        shutil.copy(f"{O}/hbm_stats/hbm_leg.json", f"{P}/final_hbm_leg_under_rocprof.json")
+if os.path.exists(f"{O}/hbm_fetch/hbm_leg_counter_collection.csv"):
+    f = [x for x in counters(f"{O}/hbm_fetch/hbm_leg_counter_collection.csv", "FETCH_SIZE") if x[2] > 1000]
+    w = [x for x in counters(f"{O}/hbm_write/hbm_leg_counter_collection.csv", "WRITE_SIZE")] if os.path.exists(f"{O}/hbm_write/hbm_leg_counter_collection.csv") else []
+    fm = sum(x[2] for x in f) / len(f); wm = (sum(x[2] for x in w) / len(w)) if w else 0.0
+    traffic = (2 * fm + wm) * 1024
+    print("hbm leg L2-miss traffic per launch (2 x FETCH + WRITE):", traffic, "launches", len(f))
+    with open(f"{P}/final_hbm_leg_pmc_fetch.csv", "w") as out:
+        out.write("counter,dispatch_id,kernel,value_KB\n")
+        for name, rows in (("FETCH_SIZE", f), ("WRITE_SIZE", w)):
+            for d, k, v in rows:
+                out.write(f"{name},{d},{k.split('(')[0][:60].replace(',', ';')},{v}\n")
+    tj["cfg5_big20_q2048"] = traffic
 # big-index FETCH_SIZE per law: the laws run in the order given on the command line, 1 untimed + 3 timed launches each
 laws = ["cfg5", "cfg5_thin", "cfg5_gen", "cfg5_tile", "r8"]
 big = {}
-for tag in ("raw", "pk1", "pk2"):
+for tag in ("raw", "nodeal", "pk1", "pk2"):
     f = f"{O}/big_fetch_{tag}/counter_collection.csv"
     if not os.path.exists(f):
         continue
@@ -66,8 +85,8 @@ if big:
             for l, v in d.items():
                 out.write(f"{l},{tag},{v:.0f}\n")
     print("big-index L2-miss bytes per launch:", {t: {l: round(v / 1e9, 2) for l, v in d.items()} for t, d in big.items()})
-    if "raw" in big:
-        tj["cfg5_big20_q2048"] = big["raw"]["cfg5"]
+    if "nodeal" in big:
+        tj["cfg5_big20_q2048_no_xcd_dealing"] = big["nodeal"]["cfg5"]
     if "pk1" in big:
         tj["cfg5_big20_q2048_packed1"] = big["pk1"]["cfg5"]
 for a, b in (("invert_bench.json", "final_invert_bench.json"), ("invert_bench_1m.json", "final_invert_bench_1m.json"), ("sem_bench.json", "final_sem_bench.json")):
