@@ -434,7 +434,8 @@ def main():
     # their top-K.  Reported next to the headline, never as `value` or `roofline`: those stay on the exhaustive path, where
     # "algorithmic bytes" are bytes actually scanned.
     pruned_leg = None
-    if n_gpus == 1 and args.variant == 0 and not args.no_impact_leg and not args.kernel_only and flags == 0:
+    st_queries = [q for q in queries if len(q.split()) == 1]   # (the workloads' words are all index terms: one word = one scored term)
+    if n_gpus == 1 and args.variant == 0 and not args.no_impact_leg and not args.kernel_only and flags == 0 and st_queries:
         t0 = time.perf_counter()
         eng.build_blockmax()
         build_s = time.perf_counter() - t0
@@ -452,11 +453,10 @@ def main():
         assert inf3.flags & nsbind.NS_INFO_PRUNED, "the pruned leg did not take the block-max body"
         assert same, "pruned results differ from the exhaustive path"
         k3 = inf3.sum_score_kernel_ms / max(inf3.timed_runs, 1)
-        single = int((np.asarray(qd["term_count"]) == nseg).sum()) if nseg == 1 else None
+        single = len(st_queries)
         # the same two ways for the batch's single-term queries ALONE (in the full batch they are not what finishes last, so
         # the batch's time hardly moves; a batch of them shows what the skipped blocks are worth)
         subset = None
-        st_queries = [q for q in queries if len(q.split()) == 1]
         if len(st_queries) >= 64:
             sqd, srefs, _ = eng.build_refs(st_queries)
             times = {}
@@ -540,9 +540,9 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_source": "L2-miss bytes per launch from the builder's rocprofv3 --pmc FETCH_SIZE pass of this command (x2 gfx950 correction), profiles/; not measured in this run",
-                "limited_by": ("instruction issue: this index (83 MB on the device) is Infinity-Cache resident, single hot lists stream at > 8 TB/s of algorithmic bytes, "
-                               "and the SIMDs' vector and scalar issue slots are 70-77 % busy (profiles/: SQ_INSTS_VALU / SQ_INSTS_SALU vs SQ_BUSY_CYCLES); see hbm_resident for the memory-bound leg")
+                "traffic_source": "L2-miss bytes per launch from the builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --kernel-only` (x2 gfx950 FETCH_SIZE correction), profiles/r03/final_cfg5_pmc_traffic.csv; not measured in this run",
+                "limited_by": ("instruction issue: this index (83 MB on the device) is cache resident — with the XCD-aware launch order the launch misses L2 for 0.3x its algorithmic bytes — "
+                               "and the SIMDs' vector and scalar issue slots are 83 % / 73 % busy (profiles/r03/final_cfg5_pmc_sq.csv: SQ_ACTIVE_INST_VALU / SQ_INSTS_SALU vs SQ_BUSY_CYCLES); see hbm_resident for the HBM-resident leg")
                               if args.config in ("cfg5", "cfg3", "cfg4") else "launch latency (a few tens of microseconds of work)",
                 "algo_bytes_per_launch": int(kinfo.algo_bytes),
                 "kernel_ms": score_ms,

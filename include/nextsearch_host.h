@@ -40,6 +40,7 @@ void nsh_engine_close(nsh_engine* e);
  * the device copy and the caches it had (the reference swaps its segments in only after every one loaded,
  * src/api_engine.cpp:76-90).  On success the device context is a NEW one: re-read nsh_engine_ctx(). */
 int  nsh_engine_reload(nsh_engine* e);
+/* The engine's last failure message.  The pointer stays valid for the CALLING thread until it asks again (a copy per thread). */
 const char* nsh_engine_error(nsh_engine* e);
 ns_ctx* nsh_engine_ctx(nsh_engine* e);
 
@@ -84,6 +85,11 @@ void nsh_engine_use_pruning(nsh_engine* e, int on);
 /* on = 0: two-list groups take the driver-stream body instead of the merge body (ns_ctx_use_merge; default 1).  Same results. */
 void nsh_engine_use_merge(nsh_engine* e, int on);
 
+/* ---- inspection (tests and tools).  NOT reload-safe: these accessors read the loaded index without taking the engine
+ * lock and hand out pointers into it, and nsh_engine_reload() replaces that index — do not call them, or use what they
+ * returned, while another thread reloads.  (The search and query-preparation entries above do take the lock, as every
+ * entry of the reference's engine takes Engine::mtx.)  Likewise an ns_batch obtained through nsh_engine_prepare belongs
+ * to the device context it was prepared on: fetch and destroy it before reloading. */
 uint32_t nsh_engine_num_segments(nsh_engine* e);
 const char* nsh_engine_segment_name(nsh_engine* e, uint32_t seg);
 int nsh_engine_segment_info(nsh_engine* e, uint32_t seg, uint32_t* n_docs, float* avgdl, uint64_t* n_postings,

@@ -1134,7 +1134,8 @@ struct ns_prep {
     std::vector<uint32_t> share_at;       // per launch position: the item's locality key (XCD dealing)
     std::vector<uint32_t> bucket_pos;     // launch position at which each fine bucket of the narrow half starts (+ the end)
     std::vector<std::vector<DevWItem>> deal_tmp;   // per host thread
-    std::vector<std::vector<uint64_t>> deal_key;
+    std::vector<std::vector<uint64_t>> deal_key, deal_alt;
+    std::vector<std::vector<uint32_t>> deal_bins;
     ForkJoin* pool = nullptr;
     ~ns_prep() { delete pool; }
 };
@@ -1608,7 +1609,13 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
         std::vector<char> unstaged;
         if (!staged) unstaged.resize(up_bytes);
         char* hb = staged ? (char*)ctx->h_up : unstaged.data();
-        const bool deal = ctx->order_mode >= 1 && auto_mode && n_class[0] >= 64;
+        // The dealing costs host time (a sort per class: +0.2 ms for cfg5's 16384 queries on 8 prepare threads).  A batch small
+        // enough to be prepared by fewer than 4 threads over a cache-resident index gains ~1 % of kernel time from it and would
+        // pay 0.3 ms of single-threaded sorting per 2048 queries — more than the batch's kernel — so it keeps the plain order
+        // (2048-query batches pipelined: 0.71 ms per batch with the dealing, 0.44 without; profiles/r03/final_e2e_*.txt).
+        uint64_t resident_bytes = 0;
+        for (const ns_seg* sg_ : ctx->segs) if (sg_) resident_bytes += sg_->n_postings * 12ull;
+        const bool deal = ctx->order_mode >= 1 && auto_mode && n_class[0] >= 64 && (width >= 4 || resident_bytes > (256ull << 20) || ctx->order_mode >= 2);
         if (deal && P.share_at.size() < n_witems) P.share_at.resize(n_witems);
         fork([&](unsigned si) {
             PrepSlice& S = P.slices[si];
@@ -1642,11 +1649,9 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
             // classes of 8 fine buckets while the index fits the 256 MiB Infinity Cache (an L2 miss is cheap there and the
             // longest-first order matters more), of 16 when it does not (20 x 1M docs: L2-miss traffic 31.6 -> 28.6 GB at
             // the same launch time; the 1M-doc index loses 3 % with 32, profiles/r03)
-            uint64_t resident = 0;
-            for (const ns_seg* sg_ : ctx->segs) if (sg_) resident += sg_->n_postings * 12ull;
-            const uint32_t shift = ctx->order_coarse_forced ? (uint32_t)ctx->order_coarse : (resident > (256ull << 20) ? 4u : 3u);
+            const uint32_t shift = ctx->order_coarse_forced ? (uint32_t)ctx->order_coarse : (resident_bytes > (256ull << 20) ? 4u : 3u);
             const uint32_t n_cls = kOrderBuckets >> shift;
-            if (P.deal_tmp.size() < width) { P.deal_tmp.resize(width); P.deal_key.resize(width); }
+            if (P.deal_tmp.size() < width) { P.deal_tmp.resize(width); P.deal_key.resize(width); P.deal_alt.resize(width); P.deal_bins.resize(width); }
             fork([&](unsigned si) {
                 std::vector<DevWItem>& tmp = P.deal_tmp[si];
                 std::vector<uint64_t>& ord = P.deal_key[si];   // (key << 32 | index in the class): sorted = stable by key
@@ -1656,7 +1661,26 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                     if (n < 16) continue;
                     ord.resize(n);
                     for (uint32_t i = 0; i < n; i++) ord[i] = ((uint64_t)P.share_at[p0 + i] << 32) | i;
-                    std::sort(ord.begin(), ord.end());
+                    if (n <= 4096) {
+                        std::sort(ord.begin(), ord.end());
+                    } else {
+                        // a large class (all thin items of a batch have about the same run time: 17 000 items in one class of
+                        // cfg5) would keep ONE prepare thread in a comparison sort for ~1 ms: two stable counting passes over
+                        // the key's halves instead (the index in the low word is ascending already)
+                        std::vector<uint64_t>& alt = P.deal_alt[si];
+                        std::vector<uint32_t>& bins = P.deal_bins[si];
+                        alt.resize(n);
+                        bins.resize(65537);
+                        for (int pass = 0; pass < 2; pass++) {
+                            const int sh = 32 + 16 * pass;
+                            std::fill(bins.begin(), bins.end(), 0u);
+                            const uint64_t* src = pass ? alt.data() : ord.data();
+                            uint64_t* dst = pass ? ord.data() : alt.data();
+                            for (uint32_t i = 0; i < n; i++) bins[((src[i] >> sh) & 0xFFFFu) + 1u]++;
+                            for (uint32_t b2 = 0; b2 < 65536; b2++) bins[b2 + 1] += bins[b2];
+                            for (uint32_t i = 0; i < n; i++) dst[bins[(src[i] >> sh) & 0xFFFFu]++] = src[i];
+                        }
+                    }
                     tmp.assign(wd + p0, wd + p1);
                     uint32_t cur[8], end[8];
                     for (uint32_t x = 0; x < 8; x++) { cur[x] = (uint32_t)((uint64_t)n * x / 8); end[x] = (uint32_t)((uint64_t)n * (x + 1) / 8); }
