@@ -17,7 +17,7 @@ eng = nsbind.Engine(idx, 0)
 laws = law_bench.laws()
 names = ["items (driver-stream body)", "super-batches", "super-batches with foreign postings", "foreign postings LOADED (windows)", "foreign postings consumed",
          "foreign chunks", "claim iterations", "rmw term passes", "driver rounds (256 loaded each)", "driver postings consumed", "terms (sum over items)",
-         "active foreign terms (sum over sb)", "driver chunks with postings", "driver chunks that probed the table", "driver postings that hit the table", "-"]
+         "active foreign terms (sum over sb)", "driver chunks with postings", "driver chunks that probed the table", "driver postings that hit the table", "foreign entries placed WITHOUT a claim (pass A)"]
 for n in (sys.argv[1] if len(sys.argv) > 1 else "cfg5_gen").split(","):
     qs, k = laws[n]
     b = eng.prepare(qs, k)
@@ -29,7 +29,7 @@ for n in (sys.argv[1] if len(sys.argv) > 1 else "cfg5_gen").split(","):
     inf = b.info()
     sb = max(out[1], 1)
     print(f"{n}: postings {inf.postings}, kernel {inf.last_score_kernel_ms:.3f} ms")
-    for i in range(15):
+    for i in range(16):
         print(f"    {names[i]:>40}: {out[i]:>12}  ({out[i] / sb:8.2f} per super-batch)")
     print(f"    foreign window utilisation {out[4] / max(out[3], 1):.3f}; lanes used in foreign chunks {out[4] / max(out[5] * 64, 1):.3f}; "
           f"driver round utilisation {out[9] / max(out[8] * 256, 1):.3f}; lanes used in driver chunks {out[9] / max(out[12] * 64, 1):.3f}; "
