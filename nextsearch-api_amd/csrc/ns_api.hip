@@ -164,6 +164,7 @@ struct ns_ctx {
     // NS_ORDER_MODE (0 = off) / NS_ORDER_COARSE (log2 of the fine buckets per class) override it for experiments; read at
     // ns_ctx_create.
     int order_mode = 1, order_coarse = 3;
+    uint32_t tile_dens64 = 16;   // doc-tile class from this many postings per 64 docs (0.25 per doc); NS_TILE_DENS64 overrides (sweeps)
     bool order_coarse_forced = false;   // NS_ORDER_COARSE given: no automatic choice
 };
 
@@ -279,6 +280,7 @@ extern "C" int ns_ctx_create(int device, ns_ctx** out) {
     }
     ctx->stream = ctx->own_stream;
     if (const char* om = std::getenv("NS_ORDER_MODE")) ctx->order_mode = std::atoi(om);
+    if (const char* td = std::getenv("NS_TILE_DENS64")) ctx->tile_dens64 = (uint32_t)std::max(1, std::atoi(td));
     if (const char* um = std::getenv("NS_MERGE")) ctx->use_merge = std::atoi(um) != 0;
     if (const char* oc = std::getenv("NS_ORDER_COARSE")) { ctx->order_coarse = std::max(0, std::min(11, std::atoi(oc))); ctx->order_coarse_forced = true; }
     if (hipStreamCreateWithFlags(&ctx->alt_stream, hipStreamNonBlocking) != hipSuccess) { ctx->alt_stream = nullptr; (void)hipGetLastError(); }
@@ -1256,7 +1258,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                     const uint64_t rest = hg.cost - hg.cmax;
                     const uint32_t nd = std::max<uint32_t>(segs[sid].n_docs, 1);
                     if (rest * 32 <= hg.cmax) hg.cls = 1;
-                    else if (hg.g.term_count >= 2 && hg.cost * 4 >= (uint64_t)nd) hg.cls = 2;
+                    else if (hg.g.term_count >= 2 && hg.cost * 64 >= (uint64_t)nd * ctx->tile_dens64) hg.cls = 2;
                     else hg.cls = 0;
                     // work estimate in units of one streamed driver posting (measured, profiles/r01): a foreign
                     // posting (claim, accumulate, read back) costs ~8x, a doc-tile posting ~2x
@@ -2262,7 +2264,7 @@ extern "C" int ns_sem_topk(ns_ctx* ctx, ns_sem* sem, const float* qvecs, uint32_
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const uint32_t dim = sem->dim, rows = sem->rows, rp = sem->rows_pad;
-    const uint32_t n_chunks = (rows + kSemChunk - 1) / kSemChunk, n_cand = n_chunks * topk;
+    const uint32_t cap = ((rows + 63) / 64) * topk;   // keys a query's scan can leave: topk per wave of 64 rows
     const uint32_t n_groups = (n_q + kSemB - 1) / kSemB;
     const uint32_t n_ban = ban_off ? ban_off[n_q] : 0;
     // per-group ban offsets, rebased
@@ -2277,8 +2279,8 @@ extern "C" int ns_sem_topk(ns_ctx* ctx, ns_sem* sem, const float* qvecs, uint32_
     std::vector<float> qpad((size_t)n_groups * kSemB * dim, 0.0f);
     std::memcpy(qpad.data(), qvecs, (size_t)n_q * dim * 4);
 
-    float *d_q = nullptr, *d_sims = nullptr, *d_osims = nullptr;
-    uint32_t *d_goff = nullptr, *d_grows = nullptr, *d_orows = nullptr, *d_ocnt = nullptr;
+    float *d_q = nullptr, *d_osims = nullptr;
+    uint32_t *d_goff = nullptr, *d_grows = nullptr, *d_orows = nullptr, *d_ocnt = nullptr, *d_count = nullptr;
     uint64_t* d_cand = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipError_t e = hipSuccess;
@@ -2287,13 +2289,13 @@ extern "C" int ns_sem_topk(ns_ctx* ctx, ns_sem* sem, const float* qvecs, uint32_
     // one block from the ctx pool for all scratch arrays (every search of a serving loop expands its query)
     size_t off = 0;
     auto place = [&](size_t bytes) { const size_t o = off; off = (off + std::max<size_t>(bytes, 1) + 255) & ~(size_t)255; return o; };
-    const size_t o_q = place(qpad.size() * 4), o_sims = place((size_t)kSemB * rp * 4), o_cand = place((size_t)kSemB * n_cand * 8), o_goff = place(goff.size() * 4),
+    const size_t o_q = place(qpad.size() * 4), o_cand = place((size_t)kSemB * cap * 8), o_goff = place(goff.size() * 4), o_count = place((size_t)kSemB * 4),
                  o_grows = place(grows.size() * 4), o_orows = place(n_pad * topk * 4), o_osims = place(n_pad * topk * 4), o_ocnt = place(n_pad * 4);
     const size_t block_bytes = off;
     char* blk = nullptr;
     chk(pool_alloc(ctx, (void**)&blk, block_bytes));
     if (e == hipSuccess) {
-        d_q = (float*)(blk + o_q); d_sims = (float*)(blk + o_sims); d_cand = (uint64_t*)(blk + o_cand); d_goff = (uint32_t*)(blk + o_goff);
+        d_q = (float*)(blk + o_q); d_cand = (uint64_t*)(blk + o_cand); d_goff = (uint32_t*)(blk + o_goff); d_count = (uint32_t*)(blk + o_count);
         d_grows = (uint32_t*)(blk + o_grows); d_orows = (uint32_t*)(blk + o_orows); d_osims = (float*)(blk + o_osims); d_ocnt = (uint32_t*)(blk + o_ocnt);
     }
     chk(hipEventCreate(&ev0));
@@ -2302,11 +2304,12 @@ extern "C" int ns_sem_topk(ns_ctx* ctx, ns_sem* sem, const float* qvecs, uint32_
         chk(hipMemcpyAsync(d_q, qpad.data(), qpad.size() * 4, hipMemcpyHostToDevice, st));
         chk(hipMemcpyAsync(d_goff, goff.data(), goff.size() * 4, hipMemcpyHostToDevice, st));
         chk(hipMemcpyAsync(d_grows, grows.data(), grows.size() * 4, hipMemcpyHostToDevice, st));
+        chk(hipMemsetAsync(d_count, 0, (size_t)kSemB * 4, st));   // k_sem_final_topk leaves it zero for the next group
         chk(hipEventRecord(ev0, st));
         for (uint32_t g = 0; g < n_groups; g++) {
-            hipLaunchKernelGGL(k_sem_sims, dim3((rows + 255) / 256), dim3(256), 0, st, sem->d_vt, rows, rp, dim, d_q + (size_t)g * kSemB * dim, d_sims);
-            hipLaunchKernelGGL(k_sem_chunk_topk, dim3(n_chunks, kSemB), dim3(256), 0, st, d_sims, rows, rp, min_sim, d_goff + (size_t)g * (kSemB + 1), d_grows, topk, n_chunks, d_cand);
-            hipLaunchKernelGGL(k_sem_final_topk, dim3(kSemB), dim3(256), 0, st, d_cand, n_cand, topk, d_orows + (size_t)g * kSemB * topk, d_osims + (size_t)g * kSemB * topk, d_ocnt + (size_t)g * kSemB);
+            hipLaunchKernelGGL(k_sem_scan_topk, dim3((rows + 255) / 256), dim3(256), 0, st, sem->d_vt, rows, rp, dim, d_q + (size_t)g * kSemB * dim, min_sim,
+                               d_goff + (size_t)g * (kSemB + 1), d_grows, topk, cap, d_cand, d_count);
+            hipLaunchKernelGGL(k_sem_final_topk, dim3(kSemB), dim3(256), 0, st, d_cand, cap, d_count, topk, d_orows + (size_t)g * kSemB * topk, d_osims + (size_t)g * kSemB * topk, d_ocnt + (size_t)g * kSemB);
         }
         chk(hipEventRecord(ev1, st));
         chk(hipGetLastError());

@@ -12,7 +12,8 @@
 // the earlier row).  The table is stored dimension-major ([dim][rows]) so that a wave's 64 rows are 64
 // consecutive floats per dimension; the query values are wave-uniform (scalar loads).
 //
-// HBM-bound: one pass over the table (rows x dim x 4 B) per group of kSemB query vectors.
+// HBM-bound: one pass over the table (rows x dim x 4 B) per group of kSemB query vectors; the selection rides in the same
+// kernel (k_sem_scan_topk) and a one-workgroup-per-query kernel picks the final top-k from the few keys it left.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -20,7 +21,6 @@
 namespace ns {
 
 constexpr int kSemB = 8;             // query vectors per pass over the table
-constexpr int kSemChunk = 8192;      // rows per selection workgroup
 constexpr int kSemMaxK = 64;
 
 __device__ __forceinline__ uint32_t sem_order_bits(float f) {
@@ -46,10 +46,29 @@ __global__ void __launch_bounds__(256) k_sem_transpose(const float* __restrict__
     }
 }
 
-__global__ void __launch_bounds__(256) k_sem_sims(const float* __restrict__ vt, uint32_t rows, uint32_t rows_pad, uint32_t dim,
-                                                  const float* __restrict__ q /* [kSemB][dim] */, float* __restrict__ sims /* [kSemB][rows_pad] */) {
+// 64-bit wave maximum; every lane gets the result
+__device__ __forceinline__ uint64_t sem_wave_max(uint64_t k) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const uint64_t o = __shfl_xor(k, d, 64);
+        k = o > k ? o : k;
+    }
+    return k;
+}
+
+// The scan WITH the selection (round 3; round 2 wrote the kSemB x rows sims out and selected in two more kernels, 24 % of a
+// group's time).  One thread owns one table row and walks the dimensions in order with kSemB query accumulators; then, per
+// query, the wave's rows that pass (sim >= min_sim, :124; not banned, :119) hand their up-to-topk best keys to the query's
+// candidate list — an atomic cursor per query; almost every wave has none and leaves after one ballot per query.
+// cand[b][0 .. count[b]): keys in arrival order (they are unique: the final selection is by key, so the order is immaterial).
+__global__ void __launch_bounds__(256) k_sem_scan_topk(const float* __restrict__ vt, uint32_t rows, uint32_t rows_pad, uint32_t dim,
+                                                       const float* __restrict__ q /* [kSemB][dim] */, float min_sim,
+                                                       const uint32_t* __restrict__ ban_off /* [kSemB + 1] */, const uint32_t* __restrict__ ban_rows,
+                                                       uint32_t topk, uint32_t cap /* keys per query */, uint64_t* __restrict__ cand /* [kSemB][cap] */,
+                                                       uint32_t* __restrict__ count /* [kSemB], zero at launch */) {
     const uint32_t r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= rows) return;
+    const bool live = r < rows;
+    const uint32_t rr = live ? r : 0u;   // lanes past the table walk row 0 and offer nothing (the wave stays whole for the shuffles)
     float acc[kSemB];
 #pragma unroll
     for (int b = 0; b < kSemB; b++) acc[b] = 0.0f;
@@ -58,28 +77,40 @@ __global__ void __launch_bounds__(256) k_sem_sims(const float* __restrict__ vt, 
     for (; i + U <= dim; i += U) {
         float v[U];
 #pragma unroll
-        for (uint32_t u = 0; u < U; u++) v[u] = vt[(size_t)(i + u) * rows_pad + r];
+        for (uint32_t u = 0; u < U; u++) v[u] = vt[(size_t)(i + u) * rows_pad + rr];
 #pragma unroll
         for (uint32_t u = 0; u < U; u++)
 #pragma unroll
             for (int b = 0; b < kSemB; b++) acc[b] = acc[b] + q[(size_t)b * dim + i + u] * v[u];   // :13 `s += a[i] * b[i]`
     }
     for (; i < dim; i++) {
-        const float v = vt[(size_t)i * rows_pad + r];
+        const float v = vt[(size_t)i * rows_pad + rr];
 #pragma unroll
         for (int b = 0; b < kSemB; b++) acc[b] = acc[b] + q[(size_t)b * dim + i] * v;
     }
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int b = 0; b < kSemB; b++) sims[(size_t)b * rows_pad + r] = acc[b];
+    for (int b = 0; b < kSemB; b++) {
+        bool ok = live && !(acc[b] < min_sim);                              // :124 (`sim < min_sim` skips; a NaN sim does not)
+        if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;              // uniform: the usual case
+        for (uint32_t j = ban_off[b]; j < ban_off[b + 1]; j++) ok = ok && ban_rows[j] != r;   // :119 (uniform bounds)
+        uint64_t key = ok ? sem_key(acc[b], r) : 0ull;
+        const uint32_t n = min((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(ok)), topk);
+        if (n == 0u) continue;
+        uint32_t pos = 0;
+        if (lane == 0) pos = atomicAdd(&count[b], n);
+        pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+        for (uint32_t t = 0; t < n; t++) {                                  // the wave's n best, best first
+            const uint64_t m = sem_wave_max(key);
+            if (lane == 0 && pos + t < cap) cand[(size_t)b * cap + pos + t] = m;
+            if (key == m) key = 0ull;                                       // keys are unique (distinct rows)
+        }
+    }
 }
 
 // workgroup argmax of a 64-bit key; every thread gets the result.  Two barriers.
 __device__ __forceinline__ uint64_t sem_block_max(uint64_t k, uint64_t* s_red) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        const uint64_t o = __shfl_xor(k, d, 64);
-        k = o > k ? o : k;
-    }
+    k = sem_wave_max(k);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = k;
     __syncthreads();
@@ -89,57 +120,13 @@ __device__ __forceinline__ uint64_t sem_block_max(uint64_t k, uint64_t* s_red) {
     return m;
 }
 
-// (chunk, query): the chunk's topk rows with sim >= min_sim that are not banned (:119-124), best first.
-__global__ void __launch_bounds__(256) k_sem_chunk_topk(const float* __restrict__ sims, uint32_t rows, uint32_t rows_pad, float min_sim,
-                                                        const uint32_t* __restrict__ ban_off /* [kSemB + 1] */, const uint32_t* __restrict__ ban_rows,
-                                                        uint32_t topk, uint32_t n_chunks, uint64_t* __restrict__ cand /* [kSemB][n_chunks][topk] keys, 0 = none */) {
-    __shared__ float s[kSemChunk];
-    __shared__ uint64_t s_red[4];
-    const uint32_t chunk = blockIdx.x, b = blockIdx.y;
-    const uint32_t base = chunk * (uint32_t)kSemChunk;
-    const float ninf = -__builtin_inff();
-    for (uint32_t j = threadIdx.x; j < (uint32_t)kSemChunk; j += 256) {
-        const uint32_t r = base + j;
-        float v = ninf;
-        if (r < rows) {
-            v = sims[(size_t)b * rows_pad + r];
-            if (v < min_sim) v = ninf;                                   // :124
-        }
-        s[j] = v;
-    }
-    __syncthreads();
-    for (uint32_t j = ban_off[b] + threadIdx.x; j < ban_off[b + 1]; j += 256) {   // :119
-        const uint32_t r = ban_rows[j];
-        if (r >= base && r < base + (uint32_t)kSemChunk) s[r - base] = ninf;
-    }
-    __syncthreads();
-    uint64_t* out = cand + ((size_t)b * n_chunks + chunk) * topk;
-    for (uint32_t round = 0; round < topk; round++) {
-        uint64_t best = 0;
-        for (uint32_t j = threadIdx.x; j < (uint32_t)kSemChunk; j += 256) {
-            const float v = s[j];
-            if (v != ninf) {
-                const uint64_t k = sem_key(v, base + j);
-                best = k > best ? k : best;
-            }
-        }
-        best = sem_block_max(best, s_red);
-        if (threadIdx.x == 0) out[round] = best;
-        if (best == 0) {   // uniform: nothing left
-            for (uint32_t t = round + 1 + threadIdx.x; t < topk; t += 256) out[t] = 0;
-            break;
-        }
-        if (threadIdx.x == 0) s[(~(uint32_t)best) - base] = ninf;
-        __syncthreads();
-    }
-}
-
-// query: the best topk of its chunks' candidates
-__global__ void __launch_bounds__(256) k_sem_final_topk(uint64_t* __restrict__ cand, uint32_t n_cand /* n_chunks * topk */, uint32_t topk,
-                                                        uint32_t* __restrict__ rows_out, float* __restrict__ sims_out, uint32_t* __restrict__ count_out) {
+// query: the best topk of the candidates its scan left
+__global__ void __launch_bounds__(256) k_sem_final_topk(uint64_t* __restrict__ cand, uint32_t cap, uint32_t* __restrict__ count /* keys the scan left per query; reset here */,
+                                                        uint32_t topk, uint32_t* __restrict__ rows_out, float* __restrict__ sims_out, uint32_t* __restrict__ count_out) {
     __shared__ uint64_t s_red[4];
     const uint32_t b = blockIdx.x;
-    uint64_t* c = cand + (size_t)b * n_cand;
+    uint64_t* c = cand + (size_t)b * cap;
+    const uint32_t n_cand = min(count[b], cap);
     uint32_t produced = 0;
     for (; produced < topk; produced++) {
         uint64_t best = 0;
@@ -158,7 +145,7 @@ __global__ void __launch_bounds__(256) k_sem_final_topk(uint64_t* __restrict__ c
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) count_out[b] = produced;
+    if (threadIdx.x == 0) { count_out[b] = produced; count[b] = 0; }   // for the next group (every thread read count[b] before the loop's first barrier)
 }
 
 }  // namespace ns
