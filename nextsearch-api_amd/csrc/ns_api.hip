@@ -164,6 +164,7 @@ struct ns_ctx {
     // NS_ORDER_MODE (0 = off) / NS_ORDER_COARSE (log2 of the fine buckets per class) override it for experiments; read at
     // ns_ctx_create.
     int order_mode = 1, order_coarse = 3;
+    uint32_t key_pct[4] = {100, 100, 100, 100};   // launch-order key of general / thin / tile / merge items in per cent (NS_KEY_PCT=g,t,d,m: sweeps)
     uint32_t tile_dens64 = 16;   // doc-tile class from this many postings per 64 docs (0.25 per doc); NS_TILE_DENS64 overrides (sweeps)
     bool order_coarse_forced = false;   // NS_ORDER_COARSE given: no automatic choice
 };
@@ -280,6 +281,10 @@ extern "C" int ns_ctx_create(int device, ns_ctx** out) {
     }
     ctx->stream = ctx->own_stream;
     if (const char* om = std::getenv("NS_ORDER_MODE")) ctx->order_mode = std::atoi(om);
+    if (const char* kp = std::getenv("NS_KEY_PCT")) {
+        unsigned a = 100, b = 100, c = 100, d = 100;
+        if (std::sscanf(kp, "%u,%u,%u,%u", &a, &b, &c, &d) >= 1) { ctx->key_pct[0] = a; ctx->key_pct[1] = b; ctx->key_pct[2] = c; ctx->key_pct[3] = d; }
+    }
     if (const char* td = std::getenv("NS_TILE_DENS64")) ctx->tile_dens64 = (uint32_t)std::max(1, std::atoi(td));
     if (const char* um = std::getenv("NS_MERGE")) ctx->use_merge = std::atoi(um) != 0;
     if (const char* oc = std::getenv("NS_ORDER_COARSE")) { ctx->order_coarse = std::max(0, std::min(11, std::atoi(oc))); ctx->order_coarse_forced = true; }
@@ -1394,6 +1399,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                     // K > 32: the streaming items pay more per posting than the work units (fitted at K = 10) say — fewer waves
                     // per CU, larger candidate buffers — so the general items start later there too (cfg3 -2.6 %, at K = 64 -2.3 %)
                     else if (auto_mode && k > 32 && hg.cls == 0) key = key * 3 / 4;
+                    if (auto_mode) key = key * ctx->key_pct[hg.merge2 ? 3 : hg.cls] / 100;   // sweeps (NS_KEY_PCT); 100 each by default
                     const bool wide = auto_mode && hg.g.term_count > 16;
                     const uint32_t bucket = order_bucket(key);
                     // what the group's items read most of: its largest list (the driver of a driver-stream item)
