@@ -1,5 +1,6 @@
 #!/bin/bash
-# Same-box A/B of two builds of the HIP library: base (tools/dbg/build_ab.sh) vs the working tree's, alternating.
+# Same-box A/B of builds of the HIP library: base (tools/dbg/build_ab.sh) vs the working tree's ("new"), alternating;
+# VARIANTS="base new x y" adds libnextsearch_hip_x.so / _y.so (built by hand next to them) to the rotation.
 set -o pipefail
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${1:-ab}
@@ -10,7 +11,7 @@ cd $R/nextsearch-api_amd && cp libnextsearch_hip.so libnextsearch_hip_new.so
 trap 'cp $R/nextsearch-api_amd/libnextsearch_hip_new.so $R/nextsearch-api_amd/libnextsearch_hip.so' EXIT
 cd $R
 for rep in 1 2 3; do
-  for v in base new; do
+  for v in ${VARIANTS:-base new}; do
     cp nextsearch-api_amd/libnextsearch_hip_$v.so nextsearch-api_amd/libnextsearch_hip.so
     echo "== $v (rep $rep)" >> $O/ab.txt
     timeout -k 10 300 python3 tools/law_bench.py --laws $LAWS --reps 8 2>&1 | grep -v "^variant\|^  *law" >> $O/ab.txt || exit 1
@@ -27,6 +28,7 @@ for ln in open("$O/ab.txt"):
     if len(f) >= 5:
         acc[f[0]][v].append(float(f[4]))
 for law, d in acc.items():
-    b = sorted(d["base"])[len(d["base"]) // 2]; n = sorted(d["new"])[len(d["new"]) // 2]
-    print(f"{law:>14}  base {b:.3f} ms  new {n:.3f} ms  {100 * (n / b - 1):+.1f} %   (base {d['base']}  new {d['new']})")
+    med = {v: sorted(x)[len(x) // 2] for v, x in d.items()}
+    b = med["base"]
+    print(f"{law:>14}  " + "  ".join(f"{v} {m:.3f} ms ({100 * (m / b - 1):+.1f} %)" for v, m in med.items()) + "   " + str(dict(d)))
 PY
