@@ -66,6 +66,9 @@ def parse_args():
     ap.add_argument("--index-dir", default="", help="reuse/generate the index here instead of a temp dir")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL over xGMI; the measured configuration) or gloo (rehearsal of the N > 1 code path with several ranks on ONE GPU)")
+    ap.add_argument("--share", type=int, default=1, choices=[0, 1, 2],
+                    help="ns_ctx_share_scores: 1 (the library's default) a batch that names its lists often enough computes each distinct list's "
+                         "BM25 term scores once per run; 0 every posting is scored in place for every query that names it; 2 always share")
     ap.add_argument("--no-impact-leg", action="store_true", help="skip the extra measurement over the optional impact streams")
     ap.add_argument("--no-hbm-leg", action="store_true", help="skip the extra measurement over the 20-segment (HBM-resident) index")
     ap.add_argument("--hbm-segments", type=int, default=20)
@@ -153,6 +156,7 @@ def run_hbm_leg(args, nsbind, np, gen, seed, docs, K, flags, device, traffic_db)
         nsbind.gen_index(bidx, S, docs, 65536, 1337, False)
         beng = nsbind.Engine(bidx, device)
         beng.set_tuning(args.variant, args.min_items, args.split)
+        beng.share_scores(args.share)
         bq = gen(Qb, seed)
         bqd, brefs, _ = beng.build_refs(bq)
         bb = nsbind.prepare_raw(beng.ctx, bqd, brefs, K, flags)
@@ -175,6 +179,8 @@ def run_hbm_leg(args, nsbind, np, gen, seed, docs, K, flags, device, traffic_db)
             "what": f"cfg5 query law, {Qb} queries over {S} segments x {docs} docs (every query scans every segment), kernel only",
             "index_bytes_on_device": int(dev_bytes), "postings_per_query": binf.postings / max(Qb, 1), "work_items": binf.n_items,
             "kernel_ms": bms, "queries_per_s_kernel": Qb / (bms * 1e-3), "timed_launches": int(binf.timed_runs),
+            "term_scores": (f"shared inside the batch: {binf.shared_lists} distinct lists, {binf.shared_postings} postings scored once per launch by k_share_scores (inside kernel_ms)"
+                            if binf.flags & nsbind.NS_INFO_SHARED else "in place"),
             "roofline": {"bound": "hbm", "achieved": bach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bach / HBM_PEAK_GBS,
                          "algo_bytes_per_launch": int(binf.algo_bytes), "traffic": tr,
                          "traffic_over_algo": (tr / binf.algo_bytes) if tr else None,
@@ -258,6 +264,7 @@ def main():
     os.environ["NS_RELOAD_WARMUP"] = "0"   # no warm-up query at reload: rocprof / PMC summaries of this command then hold the batch launches only
     eng = nsbind.Engine(index_dir, local_rank)
     eng.set_tuning(args.variant, args.min_items, args.split)
+    eng.share_scores(args.share)
     # the step's INPUT: the shard's term refs in host memory, in the C-ABI's layout (tokenise + lexicon probes + idf done)
     qd, refs, usable = eng.build_refs(queries)
     assert usable.all()
@@ -282,6 +289,29 @@ def main():
     kb.close()
     score_ms = kinfo.sum_score_kernel_ms / max(kinfo.timed_runs, 1)
     total_ms = kinfo.sum_total_ms / max(kinfo.timed_runs, 1)
+    shared = bool(kinfo.flags & nsbind.NS_INFO_SHARED)
+    # the same batch with sharing off (every posting scored in place, once per query that names it): reported next to the roofline
+    in_place_leg = None
+    if shared and not args.kernel_only:
+        eng.share_scores(0)
+        pb = nsbind.prepare_raw(eng.ctx, qd, refs, K, flags)
+        for _ in range(max(args.warmup, 2)):
+            pb.run(timed=False)
+        pb.sync()
+        for _ in range(args.steps):
+            pb.run(timed=True)
+        pb.sync()
+        pinf = pb.info()
+        p_hits, p_nhits, p_found = pb.fetch()
+        pb.close()
+        eng.share_scores(args.share)
+        assert not (pinf.flags & (nsbind.NS_INFO_SHARED | nsbind.NS_INFO_IMPACTS))
+        assert p_hits.tobytes() == k_hits.tobytes() and p_nhits.tobytes() == k_nhits.tobytes() and p_found.tobytes() == k_found.tobytes(), \
+            "shared term scores changed the results"
+        pms = pinf.sum_score_kernel_ms / max(pinf.timed_runs, 1)
+        in_place_leg = {"what": "same batch, kernel only, ns_ctx_share_scores(0): the BM25 term score of a posting evaluated once per query that names its list",
+                        "kernel_ms": pms, "achieved": pinf.algo_bytes / (pms * 1e-3) / 1e9 if pms > 0 else 0.0,
+                        "frac": (pinf.algo_bytes / (pms * 1e-3) / 1e9 / HBM_PEAK_GBS) if pms > 0 else 0.0, "identical_results": True}
 
     # ---- value leg: K pipelined steps at the C-ABI boundary ----
     # A serving loop sees a different batch every step: the steps rotate over ROT distinct batches of the same query law and
@@ -531,10 +561,13 @@ def main():
                 "kernel_variant": args.variant,
                 "work_items": kinfo.n_items,
                 "index_side_data": "skip tables for lists of >= n_docs/512 postings (4 B per list and 1024-doc cell, built at reload from the uploaded postings); no impact / packed streams in this leg",
+                "term_scores": (f"shared inside the batch: the {kinfo.shared_lists} distinct lists ({kinfo.shared_postings} postings) the batch names are scored once per step by k_share_scores, "
+                                f"in front of the scoring kernel and inside the timed region ({kinfo.postings / max(kinfo.shared_postings, 1):.0f} uses per distinct posting); nothing is kept between steps")
+                               if shared else "in place: every posting scored once per query that names its list",
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_uscore" if args.variant == 0 else "k_dscore" if args.variant in (12, 13, 14, 15, 16, 17) else "k_tscore" if args.variant in (18, 19, 20) else "k_score",
+                "kernel": "k_share_scores + k_uscore" if (args.variant == 0 and shared) else "k_uscore" if args.variant == 0 else "k_dscore" if args.variant in (12, 13, 14, 15, 16, 17) else "k_tscore" if args.variant in (18, 19, 20) else "k_score",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -547,7 +580,8 @@ def main():
                 "algo_bytes_per_launch": int(kinfo.algo_bytes),
                 "kernel_ms": score_ms,
                 "all_kernels_ms": total_ms,
-                "measured": "HIP events on the ctx stream around every scoring launch of the kernel leg (descriptors resident, one batch at a time)",
+                "measured": "HIP events on the ctx stream around every scoring launch of the kernel leg (descriptors resident, one batch at a time)"
+                            + ("; the span holds BOTH kernels of a step: k_share_scores (the batch's distinct lists scored once) and k_uscore" if shared else ""),
             },
             "kernel_only": {"value": Qr * n_gpus * args.steps / kernel_elapsed, "unit": "queries/s", "ms_per_step": kernel_elapsed / args.steps * 1e3,
                             "what": "device-only: the prepared batch re-run with descriptors resident in HBM (round 1's `value`)"},
@@ -561,6 +595,8 @@ def main():
                 line["cpu_baselines"] = allcb
         if hbm_leg is not None:
             line["hbm_resident"] = hbm_leg
+        if in_place_leg is not None:
+            line["in_place"] = in_place_leg
         if impact_leg is not None:
             line["impact_stream"] = impact_leg
         if pruned_leg is not None:

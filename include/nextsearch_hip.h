@@ -41,6 +41,7 @@ extern "C" {
 #define NS_FLAG_AND     1u   /* extension (BASELINE config 2): keep docs matched by every term ref of their segment */
 #define NS_INFO_IMPACTS 0x100u /* ns_batch_info.flags only (output): the batch reads impact streams (ns_segment_build_impacts) */
 #define NS_INFO_PACKED  0x200u /* ns_batch_info.flags only (output): the batch's driver streams read the packed posting blocks (ns_segment_build_packed) */
+#define NS_INFO_SHARED  0x800u /* ns_batch_info.flags only (output): the batch computes the BM25 term scores of its distinct lists once per run (ns_ctx_share_scores) */
 #define NS_INFO_PRUNED  0x400u /* ns_batch_info.flags only (output): some single-term queries of the batch skip posting blocks by their block maxima (ns_ctx_use_pruning) */
 
 typedef struct ns_ctx   ns_ctx;
@@ -84,9 +85,10 @@ typedef struct ns_batch_info {
     float    last_score_kernel_ms; /* HIP-event time of the scoring kernel in the last timed run, <0 if none */
     float    last_total_ms;        /* HIP-event time of all kernels of the last timed run, <0 if none */
     uint32_t timed_runs;           /* timed runs accumulated since prepare (read back at every sync) */
-    uint32_t reserved;
-    double   sum_score_kernel_ms;  /* sum over timed runs of the scoring kernel's HIP-event time */
+    uint32_t shared_lists;         /* distinct posting lists whose term scores the batch computes once per run (0: it does not share) */
+    double   sum_score_kernel_ms;  /* sum over timed runs of the scoring kernel's HIP-event time (with the shared-score kernel in front of it, if any) */
     double   sum_total_ms;         /* sum over timed runs of first-kernel-start .. last-kernel-end */
+    uint64_t shared_postings;      /* postings of those lists */
 } ns_batch_info;
 
 /* ---- context ------------------------------------------------------------------------------ */
@@ -193,6 +195,21 @@ int ns_ctx_use_pruning(ns_ctx* ctx, int on);
  * the two-list merge body (default: on = 1; both sorted lists advance in lockstep, B's postings find their docs among A's
  * round by a lower bound in LDS: src/api_engine.cpp:449-481 for two lists without a hash table).  Same results. */
 int ns_ctx_use_merge(ns_ctx* ctx, int on);
+/* Shared term scores.  The reference evaluates the BM25 term score of a posting, src/api_engine.cpp:477-479, once per query
+ * that names the posting's list (src/api_engine.cpp:449,464-481: every request walks its lists alone).  The score depends on
+ * the list and on the list's idf, not on the query, and a BATCH names the same lists again and again (16384 queries of
+ * BASELINE's cfg5 law: ~50 000 term refs, ~40 000 distinct lists, the 32 most frequent ~460 times each).  A sharing batch
+ * computes the scores of each DISTINCT list it names once per run — a kernel in front of its scoring kernel, inside
+ * ns_batch_run, reading the uploaded {docId, tf} postings and norms and writing {docId, score} (8 B of HBM per posting of
+ * the segment, allocated by the first sharing batch) — and its scoring bodies read those.  Nothing is carried from one
+ * batch to the next and nothing outlives the run: this is common-subexpression elimination inside one batch, with the
+ * reference's operations in the reference's order, and hits, order, nhits, found and score bits are identical (tests run
+ * both ways).  mode 1 (default): a batch shares when it scans >= 4 Mi postings and names each distinct posting >= 48 times on
+ * average (measured break-even on MI355X: the extra kernel costs ~6 ps per distinct posting, sharing saves ~0.12 ps per use); mode 2: every batch that can (tests); mode 0: never.  A batch never shares when a list of it overlaps another
+ * list ever shared in the segment, when a segment of it carries an optional impact stream that lacks one of its lists, or
+ * when a list's idf differs from the one a live sharing batch uses; it then scores every posting in place, as with mode 0.
+ * ns_batch_info reports NS_INFO_SHARED, shared_lists and shared_postings; sum_score_kernel_ms covers both kernels. */
+int ns_ctx_share_scores(ns_ctx* ctx, int mode);
 
 /* ---- one-shot search (host buffers in, host buffers out) ------------------------------------ */
 /* hits_out: Q*K entries, query-major, best first: score desc, then seg_id asc, then doc_id asc

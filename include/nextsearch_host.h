@@ -84,6 +84,9 @@ int  nsh_engine_build_blockmax(nsh_engine* e);
 void nsh_engine_use_pruning(nsh_engine* e, int on);
 /* on = 0: two-list groups take the driver-stream body instead of the merge body (ns_ctx_use_merge; default 1).  Same results. */
 void nsh_engine_use_merge(nsh_engine* e, int on);
+/* Shared term scores (include/nextsearch_hip.h: ns_ctx_share_scores) on every device context of the engine: 0 never, 1 (default)
+ * batches that name each distinct list often enough compute its BM25 term scores once per run, 2 every batch that can.  Same results. */
+void nsh_engine_share_scores(nsh_engine* e, int mode);
 
 /* ---- inspection (tests and tools).  NOT reload-safe: these accessors read the loaded index without taking the engine
  * lock and hand out pointers into it, and nsh_engine_reload() replaces that index — do not call them, or use what they

@@ -15,6 +15,7 @@
 #include <numeric>
 #include <string>
 #include <thread>
+#include <map>
 #include <vector>
 
 #include "../../include/nextsearch_hip.h"
@@ -104,6 +105,19 @@ struct ns_seg {
             if (e.first == 0xFFFFFFFFu) return 0;
         }
     }
+    // Shared term scores (ns_ctx_share_scores): every list a sharing batch ever built into d_impacts, first -> count.  Lists
+    // that overlap another one are refused (two builders would write the same postings with different values).
+    std::map<uint32_t, uint32_t> share_lists;
+    bool share_admit(uint32_t first, uint32_t count) {
+        auto it = share_lists.lower_bound(first);
+        if (it != share_lists.end() && (it->first == first ? it->second != count : (uint64_t)first + count > it->first)) return false;
+        if (it != share_lists.begin() && (it == share_lists.end() || it->first != first)) {
+            auto pv = std::prev(it);
+            if ((uint64_t)pv->first + pv->second > first) return false;
+        }
+        share_lists.emplace(first, count);
+        return true;
+    }
     bool imp_has(uint32_t first, uint32_t count, uint32_t idf_bits) const {
         if (imp_tab.empty()) return false;
         const size_t mask = imp_tab.size() - 1;
@@ -153,6 +167,18 @@ struct ns_ctx {
     // pinned result buffers for batches in flight (NS_RUN_FETCH): one per batch between its run and its fetch
     struct DownSlot { void* p = nullptr; size_t cap = 0; bool busy = false; };
     std::vector<DownSlot> down_slots;
+    // Shared term scores (ns_ctx_share_scores): 0 off; 1 a batch whose term refs name each distinct list often enough computes
+    // every list's BM25 term scores ONCE (k_share_scores, in front of the scoring kernel, on every run) and scores from
+    // {docId, score}; 2 every batch that can (tests).  The registry maps (segment, first posting) to the list's count and idf and
+    // to the last batch that listed it; `live_shared` counts the sharing batches alive: an idf may only change while it is 0.
+    int share_mode = 1;
+    uint32_t share_ratio = 48;           // share when postings >= share_ratio x distinct postings (below ~50 uses per posting the extra kernel costs what it saves) ...
+    uint64_t share_min_postings = 4u << 20;   // ... and the batch scans at least this many postings
+    struct ShareEnt { uint64_t key = ~0ull; uint32_t count = 0, idf_bits = 0, epoch = 0; bool bad = false; };
+    std::vector<ShareEnt> share_tab;     // open-addressed, size a power of two (or 0)
+    size_t share_n = 0;
+    uint32_t share_epoch = 0;
+    uint32_t live_shared = 0;
     bool use_impacts = true;   // batches take the impact stream when every list they touch has one (ns_ctx_use_impacts)
     int use_packed = 1;        // 0 off; 1, 2: batches read the packed stream when every segment they touch has one (ns_ctx_use_packed)
     bool use_skips = true;     // doc-tile groups walk the skip grid when their lists have skip tables (ns_ctx_use_skips)
@@ -287,6 +313,9 @@ extern "C" int ns_ctx_create(int device, ns_ctx** out) {
     }
     if (const char* td = std::getenv("NS_TILE_DENS64")) ctx->tile_dens64 = (uint32_t)std::max(1, std::atoi(td));
     if (const char* um = std::getenv("NS_MERGE")) ctx->use_merge = std::atoi(um) != 0;
+    if (const char* sm = std::getenv("NS_SHARE")) ctx->share_mode = std::max(0, std::min(2, std::atoi(sm)));
+    if (const char* sr = std::getenv("NS_SHARE_RATIO")) ctx->share_ratio = (uint32_t)std::max(1, std::atoi(sr));
+    if (const char* sp = std::getenv("NS_SHARE_MIN")) ctx->share_min_postings = (uint64_t)std::max(0ll, std::atoll(sp));
     if (const char* oc = std::getenv("NS_ORDER_COARSE")) { ctx->order_coarse = std::max(0, std::min(11, std::atoi(oc))); ctx->order_coarse_forced = true; }
     if (hipStreamCreateWithFlags(&ctx->alt_stream, hipStreamNonBlocking) != hipSuccess) { ctx->alt_stream = nullptr; (void)hipGetLastError(); }
     {
@@ -614,6 +643,7 @@ extern "C" int ns_segment_build_impacts(ns_ctx* ctx, ns_seg* seg, const uint64_t
     if (seg->id >= ctx->segs.size() || ctx->segs[seg->id] != seg) return fail(ctx, NS_E_INVAL, "segment does not belong to this ctx");
     if (n_lists && (!byte_off || !counts || !idfs)) return fail(ctx, NS_E_INVAL, "null list arrays");
     if (!n_lists || !seg->n_postings) return NS_OK;
+    if (ctx->live_shared) return fail(ctx, NS_E_STATE, "ns_segment_build_impacts: %u batch(es) that compute shared term scores into the same buffer are alive; destroy them first", ctx->live_shared);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     struct L { uint32_t first, count; float idf; };
     std::vector<L> lists;
@@ -670,6 +700,83 @@ extern "C" int ns_segment_build_impacts(ns_ctx* ctx, ns_seg* seg, const uint64_t
     seg->imp_tab.swap(tab);
     seg->imp_lists = distinct;
     return NS_OK;
+}
+
+// ---- shared term scores -------------------------------------------------------------------------------------------
+// A batch names the same posting list many times (cfg5: 16384 queries draw ~50 000 term refs from ~40 000 distinct lists, and
+// the 32 hot lists ~460 times each): the BM25 term score of a posting, src/api_engine.cpp:477-479, depends on the list and on
+// the list's idf, not on the query.  A sharing batch therefore computes the scores of every DISTINCT list it names once, in
+// this kernel, in front of its scoring kernel and on every run (nothing is kept from one batch for the next: a later batch
+// finds the buffer as if it had never been written), and the scoring bodies read {docId, score bits} — their IMP form, the one
+// that serves the optional impact stream — instead of {docId, tf} + norm.  Same operations, same order, same bits: the
+// division below is the compiler's correctly rounded one, which ns_div_short reproduces exactly where it is used.
+// 1024 consecutive postings of the batch's build order per workgroup; a thread finds the list of each of its postings by
+// binary search between the lists that hold the workgroup's first and last posting.
+__global__ void __launch_bounds__(256) k_share_scores(const DevShare* __restrict__ sh, uint32_t n_lists, const DevSeg* __restrict__ segs) {
+    const uint32_t total = sh[n_lists].before;
+    const uint32_t base = blockIdx.x * 1024u;
+    if (base >= total) return;
+    const uint32_t last = min(base + 1023u, total - 1u);
+    __shared__ uint32_t s_lo, s_hi;
+    if (threadIdx.x < 2) {
+        const uint32_t want = threadIdx.x == 0 ? base : last;   // the list l with sh[l].before <= want < sh[l + 1].before
+        uint32_t lo = 0, hi = n_lists;
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (sh[mid].before <= want) lo = mid; else hi = mid;
+        }
+        if (threadIdx.x == 0) s_lo = lo; else s_hi = lo;
+    }
+    __syncthreads();
+    const uint32_t l0 = s_lo, l1 = s_hi;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t p = base + (uint32_t)j * 256u + threadIdx.x;
+        if (p > last) continue;
+        uint32_t lo = l0, hi = l1 + 1u;
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (sh[mid].before <= p) lo = mid; else hi = mid;
+        }
+        const DevShare L = sh[lo];
+        const DevSeg& sg = segs[L.seg];
+        const uint64_t at = (uint64_t)L.first + (p - L.before);
+        const uint2 pv = sg.postings[at];
+        const float tf = (float)pv.y;
+        const float den = tf + sg.pnorm[at];
+        const float num = L.idf * (tf * (1.2f + 1.0f));
+        const_cast<uint2*>(sg.impacts)[at] = make_uint2(pv.x, __float_as_uint(num / den));
+    }
+}
+
+extern "C" int ns_ctx_share_scores(ns_ctx* ctx, int mode) {
+    if (!ctx) return fail(nullptr, NS_E_INVAL, "ns_ctx_share_scores: ctx is NULL");
+    if (mode < 0 || mode > 2) return fail(ctx, NS_E_INVAL, "ns_ctx_share_scores: mode %d outside [0, 2]", mode);
+    ctx->share_mode = mode;
+    return NS_OK;
+}
+
+// the registry entry of list (seg, first): found or made (the table doubles at half load; entries are never removed)
+static ns_ctx::ShareEnt& share_entry(ns_ctx* ctx, uint32_t seg, uint32_t first, bool& fresh) {
+    if (ctx->share_tab.empty() || ctx->share_n * 2 >= ctx->share_tab.size()) {
+        std::vector<ns_ctx::ShareEnt> bigger(std::max<size_t>(1024, ctx->share_tab.size() * 2));
+        const size_t m = bigger.size() - 1;
+        for (const auto& e : ctx->share_tab)
+            if (e.key != ~0ull) {
+                size_t h = (size_t)((e.key * 0x9E3779B97F4A7C15ull) >> 20) & m;
+                while (bigger[h].key != ~0ull) h = (h + 1) & m;
+                bigger[h] = e;
+            }
+        ctx->share_tab.swap(bigger);
+    }
+    const uint64_t key = ((uint64_t)seg << 32) | first;
+    const size_t m = ctx->share_tab.size() - 1;
+    size_t h = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 20) & m;
+    for (;; h = (h + 1) & m) {
+        ns_ctx::ShareEnt& e = ctx->share_tab[h];
+        if (e.key == key) { fresh = false; return e; }
+        if (e.key == ~0ull) { e.key = key; ctx->share_n++; fresh = true; return e; }
+    }
 }
 
 extern "C" int ns_segment_build_packed(ns_ctx* ctx, ns_seg* seg) {
@@ -965,6 +1072,10 @@ struct ns_batch {
     int pk = 0;            // every segment of the batch has a packed posting stream and the ctx wants it: 1 = packed docIds + tf, norms from the fp32 norm stream; 2 = norms through the 16-bit norm index (ns_ctx_use_packed)
     bool pruned = false;   // some single-term items take the block-max pruned body (ns_ctx_use_pruning)
     bool imp = false;      // every list of the batch has an impact stream: the kernels read {docId, score} instead of {docId, tf} + norm
+    bool shared = false;   // ... because the batch computes them itself, once per distinct list and run (k_share_scores; ns_ctx_share_scores)
+    uint32_t n_share = 0;          // distinct lists the batch builds
+    uint64_t share_postings = 0;   // their postings
+    DevShare* d_share = nullptr;   // n_share + 1 entries
     // device
     DevItem* d_items = nullptr;
     DevWItem* d_witems = nullptr;
@@ -1059,6 +1170,7 @@ extern "C" void ns_batch_destroy(ns_batch* b) {
     else (void)hipStreamSynchronize(b->st);
     if (b->ctx->down_owner == b) b->ctx->down_owner = nullptr;
     if (b->down_slot >= 0) b->ctx->down_slots[(size_t)b->down_slot].busy = false;
+    if (b->shared && b->ctx->live_shared) b->ctx->live_shared--;
     for (auto& blk : b->blocks) pool_free(b->ctx, blk.first, blk.second);
     for (auto& e : b->ev_pool) if (e) (void)hipEventDestroy(e);
     if (b->done) (void)hipEventDestroy(b->done);
@@ -1138,6 +1250,7 @@ struct PrepSlice {
 
 struct ns_prep {
     std::vector<PrepSlice> slices;
+    std::vector<DevShare> share_build;    // shared term scores: the distinct lists the batch builds, in build order
     std::vector<uint32_t> share_at;       // per launch position: the item's locality key (XCD dealing)
     std::vector<uint32_t> bucket_pos;     // launch position at which each fine bucket of the narrow half starts (+ the end)
     std::vector<std::vector<DevWItem>> deal_tmp;   // per host thread
@@ -1304,6 +1417,78 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
         all_pk = all_pk && S.all_pk;
     }
     if (bounds_total >= (1ull << 32)) return fail(ctx, NS_E_INVAL, "batch too large: %llu boundary entries; split the batch", (unsigned long long)bounds_total);
+
+    // ---- shared term scores (ns_ctx_share_scores; k_share_scores): the batch's distinct lists, each listed once, in the
+    // order the term refs name them.  A list is refused — and the batch then scores every posting in place, as it
+    // always did — when it overlaps another list ever shared in its segment (two builders, one posting), when the segment
+    // carries an optional impact stream that does not hold exactly this list with this idf (the stream is not the batch's
+    // to overwrite), or when its idf differs from the one a LIVE sharing batch built it with (that batch may run again).
+    std::vector<DevShare>& share_build = P.share_build;
+    share_build.clear();
+    uint64_t share_postings = 0;
+    bool shared = false;
+    if (!all_imp && want_imp && ctx->share_mode != 0 && !all_pk && postings_total > 0 &&
+        (ctx->share_mode == 2 || postings_total >= ctx->share_min_postings)) {
+        shared = true;
+        if (++ctx->share_epoch == 0) {   // the batch counter wrapped: no entry may look like this batch's
+            for (auto& en : ctx->share_tab) en.epoch = 0;
+            ctx->share_epoch = 1;
+        }
+        const uint32_t epoch = ctx->share_epoch;
+        for (unsigned sl = 0; sl < width && shared; sl++) {
+            const std::vector<DevTerm>& dts = P.slices[sl].dterms;
+            for (size_t ti = 0; ti < dts.size(); ti++) {
+                // the registry is a few MB and every probe of it a cache miss: the probe of the term 8 ahead is requested now
+                if (ti + 8 < dts.size() && !ctx->share_tab.empty()) {
+                    const uint64_t k8 = ((uint64_t)dts[ti + 8].seg << 32) | (uint32_t)dts[ti + 8].list_off;
+                    __builtin_prefetch(&ctx->share_tab[(size_t)((k8 * 0x9E3779B97F4A7C15ull) >> 20) & (ctx->share_tab.size() - 1)]);
+                }
+                const DevTerm& t = dts[ti];
+                if (!t.count) continue;
+                ns_seg* sg = ctx->segs[t.seg];
+                uint32_t ib; std::memcpy(&ib, &t.idf, 4);
+                const uint32_t first = (uint32_t)t.list_off;
+                if (sg->imp_lists) {
+                    if (sg->imp_has(first, t.count, ib)) continue;   // the optional stream holds this list already
+                    shared = false; break;
+                }
+                bool fresh = false;
+                ns_ctx::ShareEnt& en = share_entry(ctx, t.seg, first, fresh);
+                if (fresh) { en.count = t.count; en.idf_bits = ib; en.epoch = 0; en.bad = !sg->share_admit(first, t.count); }
+                if (en.bad || en.count != t.count) { shared = false; break; }
+                if (en.idf_bits != ib) {
+                    if (ctx->live_shared || en.epoch == epoch) { shared = false; break; }
+                    en.idf_bits = ib;
+                }
+                if (en.epoch != epoch) {
+                    en.epoch = epoch;
+                    if (share_postings + t.count >= (1ull << 32)) { shared = false; break; }
+                    share_build.push_back(DevShare{first, t.count, t.idf, t.seg, (uint32_t)share_postings});
+                    share_postings += t.count;
+                    // (a batch that cannot reach the ratio gives up here: the frequent lists come early, and with them the verdict)
+                    if (ctx->share_mode == 1 && share_postings * ctx->share_ratio > postings_total) { shared = false; break; }
+                }
+            }
+        }
+        if (shared && ctx->share_mode == 1 && postings_total < (uint64_t)ctx->share_ratio * share_postings) shared = false;
+        for (size_t i = 0; shared && i < share_build.size(); i++) {   // the score buffers of the segments the batch builds into
+            ns_seg* sg = ctx->segs[share_build[i].seg];
+            if (!sg->d_impacts) {
+                const size_t nb = (size_t)(sg->n_postings + kPadPostings) * 8;
+                hipError_t ea = hipMalloc((void**)&sg->d_impacts, nb);
+                if (ea == hipSuccess) ea = hipMemsetAsync(sg->d_impacts, 0xFF, nb, ctx->stream);   // docId ~0: never taken
+                if (ea == hipSuccess) ea = hipStreamSynchronize(ctx->stream);
+                if (ea != hipSuccess) {   // no room for the scores: the batch scores in place
+                    if (sg->d_impacts) (void)hipFree(sg->d_impacts);
+                    sg->d_impacts = nullptr; (void)hipGetLastError();
+                    shared = false;
+                }
+            }
+            if (shared) segs[share_build[i].seg].impacts = sg->d_impacts;
+        }
+        if (shared) all_imp = true;
+        else { share_build.clear(); share_postings = 0; }
+    }
 
     // ---- work items.  A group is split into doc ranges (a) so that no single worker carries more
     // than ~split_postings units of estimated work (the longest item bounds the batch's tail; launch
@@ -1525,6 +1710,12 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
     b->postings = postings_total;
     b->direct = direct;
     b->imp = all_imp && postings_total > 0;
+    if (shared) {
+        b->shared = true;
+        b->n_share = (uint32_t)share_build.size();
+        b->share_postings = share_postings;
+        ctx->live_shared++;
+    }
     b->pk = (all_pk && postings_total > 0) ? ctx->use_packed : 0;
     for (unsigned s2 = 0; s2 < width; s2++) b->pruned = b->pruned || P.slices[s2].any_pruned;
 
@@ -1548,6 +1739,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
     const size_t o_queries = place(dq.size() * sizeof(dq[0]));
     const size_t o_segs = place(segs.size() * sizeof(segs[0]));
     const size_t o_wideq = place(wide_q.size() * 4);
+    const size_t o_share = place(shared ? (share_build.size() + 1) * sizeof(DevShare) : 0);
     const size_t up_bytes = off;
     const size_t o_bounds = place(bounds_total * 4);
     size_t o_phits = 0, o_pnhits = 0, o_pfound = 0, o_heads = 0;
@@ -1570,6 +1762,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
         b->d_queries = (decltype(b->d_queries))(base + o_queries);
         b->d_segs = (decltype(b->d_segs))(base + o_segs);
         b->d_wide_q = (uint32_t*)(base + o_wideq);
+        b->d_share = (DevShare*)(base + o_share);
         b->d_bounds = (uint32_t*)(base + o_bounds);
         if (!direct) {
             b->d_part_hits = (Hit*)(base + o_phits);
@@ -1703,6 +1896,11 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
         if (n_items) std::memcpy(hb + o_items, sorted_items.data(), (size_t)n_items * sizeof(DevItem));
         if (!segs.empty()) std::memcpy(hb + o_segs, segs.data(), segs.size() * sizeof(segs[0]));
         if (!wide_q.empty()) std::memcpy(hb + o_wideq, wide_q.data(), wide_q.size() * 4);
+        if (shared) {
+            std::memcpy(hb + o_share, share_build.data(), share_build.size() * sizeof(DevShare));
+            const DevShare sentinel{0u, 0u, 0.0f, 0u, (uint32_t)share_postings};
+            std::memcpy(hb + o_share + share_build.size() * sizeof(DevShare), &sentinel, sizeof(DevShare));
+        }
         if (staged) {
             // a small upload is pulled by a kernel (the pinned buffer is device-addressable): a DMA-engine copy
             // followed by a kernel costs ~11 us of cross-engine hand-over, more than the copy itself
@@ -1779,6 +1977,9 @@ extern "C" int ns_batch_run(ns_batch* b, int run_flags) {
     if (b->n_bgroups)
         hipLaunchKernelGGL(k_bounds, dim3(b->n_bgroups), dim3(128), 0, st, b->d_groups, b->d_terms, b->d_segs, b->d_bounds, b->tile_docs);
     if (timed) HIPCHK(ctx, hipEventRecord(ev[1], st));
+    // shared term scores: every distinct list of the batch once, on every run, inside the scoring kernel's timed span
+    if (b->shared && b->n_share)
+        hipLaunchKernelGGL(k_share_scores, dim3((uint32_t)((b->share_postings + 1023) / 1024)), dim3(256), 0, st, b->d_share, b->n_share, b->d_segs);
     Hit* sh = b->direct ? b->o_hits : b->d_part_hits;
     uint32_t* sn = b->direct ? b->o_nhits : b->d_part_nhits;
     uint64_t* sf = b->direct ? b->o_found : b->d_part_found;
@@ -2001,7 +2202,10 @@ extern "C" int ns_batch_get_info(ns_batch* b, ns_batch_info* info) {
     info->n_term_refs = b->n_terms;
     info->tile_docs = b->tile_docs;
     info->k = b->K;
-    info->flags = b->flags | (b->imp ? NS_INFO_IMPACTS : 0u) | (b->pk ? NS_INFO_PACKED : 0u) | (b->pruned ? NS_INFO_PRUNED : 0u);
+    info->flags = b->flags | (b->imp ? NS_INFO_IMPACTS : 0u) | (b->pk ? NS_INFO_PACKED : 0u) | (b->pruned ? NS_INFO_PRUNED : 0u) |
+                  (b->shared ? NS_INFO_SHARED : 0u);
+    info->shared_lists = b->n_share;
+    info->shared_postings = b->share_postings;
     info->last_score_kernel_ms = b->last_score_ms;
     info->last_total_ms = b->last_total_ms;
     info->timed_runs = b->timed_runs;

@@ -67,6 +67,17 @@ struct DevTerm {
     uint32_t bmx;        // 0: no block maxima (or pruning off); else 1 + index of the list's first entry in DevSeg::blockmax
 };
 
+// One DISTINCT posting list of a batch whose term scores are computed once for the whole batch (k_share_scores; ns_api.hip
+// "shared term scores"): the list's place in its segment, its idf, and the number of postings of the lists before it in the
+// batch's build order.  The array ends with a sentinel whose `before` is the total.
+struct DevShare {
+    uint32_t first;      // first posting (index into DevSeg::postings / DevSeg::impacts)
+    uint32_t count;
+    float    idf;
+    uint32_t seg;
+    uint32_t before;     // postings of the lists in front of this one
+};
+
 // Work item == one workgroup of k_score: one (query, segment) term group over a range of doc tiles.
 struct DevItem {
     uint64_t bounds_off;   // start of this group's [tile][term] boundary table

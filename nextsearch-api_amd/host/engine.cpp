@@ -296,6 +296,12 @@ void Engine::use_merge(bool on) {
     for (auto& r : replicas_) ns_ctx_use_merge(r.ctx, on ? 1 : 0);
 }
 
+void Engine::share_scores(int mode) {
+    std::lock_guard<std::recursive_mutex> lock(mtx_);
+    if (ctx_) ns_ctx_share_scores(ctx_, mode);
+    for (auto& r : replicas_) ns_ctx_share_scores(r.ctx, mode);
+}
+
 void Engine::use_packed(int mode) {
     std::lock_guard<std::recursive_mutex> lock(mtx_);
     if (ctx_) ns_ctx_use_packed(ctx_, mode);

@@ -99,6 +99,8 @@ public:
     void use_pruning(bool on);
     // groups of exactly two lists: the two-list merge body (default) or the driver-stream body like every other group
     void use_merge(bool on);
+    // ns_ctx_share_scores on every device context: 0 never, 1 (default) batches that name their lists often enough, 2 always
+    void share_scores(int mode);
     void use_packed(int mode);   // 0 off, 1 packed docIds + tf with the fp32 norm stream (default), 2 norms through the 16-bit index
     std::string search(const std::string& query, int k);        // include/api_engine.hpp:66 (JSON text, dump(2) layout)
     // Search-result cache around search() (src/api_engine.cpp:190-250,:380-385,:539): key "query|K", at most 2600

@@ -377,6 +377,8 @@ extern "C" void nsh_engine_use_pruning(nsh_engine* e, int on) { try { if (e) e->
 }
 extern "C" void nsh_engine_use_merge(nsh_engine* e, int on) { try { if (e) e->eng.use_merge(on != 0); } NSH_CATCH_VOID(e, "nsh_engine_use_merge")
 }
+extern "C" void nsh_engine_share_scores(nsh_engine* e, int mode) { try { if (e) e->eng.share_scores(mode); } NSH_CATCH_VOID(e, "nsh_engine_share_scores")
+}
 extern "C" void nsh_engine_use_skips(nsh_engine* e, int on) { try { if (e) e->eng.use_skips(on != 0);  } NSH_CATCH_VOID(e, "nsh_engine_use_skips")
 }
 extern "C" void nsh_engine_use_impacts(nsh_engine* e, int on) { try { if (e) e->eng.use_impacts(on != 0);  } NSH_CATCH_VOID(e, "nsh_engine_use_impacts")

@@ -22,6 +22,7 @@ NS_FLAG_AND = 1
 NS_INFO_IMPACTS = 0x100
 NS_INFO_PACKED = 0x200
 NS_INFO_PRUNED = 0x400
+NS_INFO_SHARED = 0x800
 NS_MAX_K = 100
 
 
@@ -42,8 +43,8 @@ class NsBatchInfo(C.Structure):
     _fields_ = [("postings", C.c_uint64), ("algo_bytes", C.c_uint64), ("n_queries", C.c_uint32),
                 ("n_items", C.c_uint32), ("n_term_refs", C.c_uint32), ("tile_docs", C.c_uint32),
                 ("k", C.c_uint32), ("flags", C.c_uint32), ("last_score_kernel_ms", C.c_float),
-                ("last_total_ms", C.c_float), ("timed_runs", C.c_uint32), ("reserved", C.c_uint32),
-                ("sum_score_kernel_ms", C.c_double), ("sum_total_ms", C.c_double)]
+                ("last_total_ms", C.c_float), ("timed_runs", C.c_uint32), ("shared_lists", C.c_uint32),
+                ("sum_score_kernel_ms", C.c_double), ("sum_total_ms", C.c_double), ("shared_postings", C.c_uint64)]
 
 
 HIT_DTYPE = np.dtype([("score", "<f4"), ("seg", "<u4"), ("doc", "<u4")])
@@ -58,7 +59,7 @@ HIP_SYMBOLS = [
     "ns_ctx_create", "ns_ctx_destroy", "ns_ctx_set_stream", "ns_last_error", "ns_device_name",
     "ns_segment_upload", "ns_segment_release", "ns_segment_upload_begin", "ns_segment_upload_append", "ns_segment_upload_end", "ns_search_batch", "ns_batch_prepare",
     "ns_batch_bind_outputs", "ns_batch_run", "ns_batch_stream", "ns_batch_gap_ms", "ns_batch_sync", "ns_batch_fetch", "ns_batch_get_info",
-    "ns_batch_destroy", "ns_set_tuning", "ns_segment_build_impacts", "ns_ctx_use_impacts", "ns_ctx_set_host_threads", "ns_ctx_set_overlap", "ns_segment_build_packed", "ns_ctx_use_packed", "ns_segment_build_skips", "ns_ctx_use_skips", "ns_segment_build_blockmax", "ns_ctx_use_pruning", "ns_ctx_use_merge",
+    "ns_batch_destroy", "ns_set_tuning", "ns_segment_build_impacts", "ns_ctx_use_impacts", "ns_ctx_set_host_threads", "ns_ctx_set_overlap", "ns_segment_build_packed", "ns_ctx_use_packed", "ns_segment_build_skips", "ns_ctx_use_skips", "ns_segment_build_blockmax", "ns_ctx_use_pruning", "ns_ctx_use_merge", "ns_ctx_share_scores",
     "ns_invert_forward", "ns_segment_upload_inverted", "ns_merge_rank_rows", "ns_sem_upload", "ns_sem_release", "ns_sem_topk",
 ]
 HOST_SYMBOLS = [
@@ -67,7 +68,7 @@ HOST_SYMBOLS = [
     "nsh_engine_segment_doc_len", "nsh_engine_segment_postings", "nsh_engine_lookup", "nsh_bm25_idf",
     "nsh_base_terms", "nsh_engine_build_refs", "nsh_engine_search_json", "nsh_free",
     "nsh_engine_search_batch", "nsh_engine_prepare", "nsh_engine_doc_metadata", "nsh_engine_hits_to_json", "nsh_engine_search_batch_json",
-    "nsh_engine_build_impacts", "nsh_engine_use_impacts", "nsh_engine_build_packed", "nsh_engine_use_packed", "nsh_engine_build_blockmax", "nsh_engine_use_pruning", "nsh_engine_use_merge", "nsh_engine_use_skips", "nsh_invert_segment", "nsh_invert_error",
+    "nsh_engine_build_impacts", "nsh_engine_use_impacts", "nsh_engine_build_packed", "nsh_engine_use_packed", "nsh_engine_build_blockmax", "nsh_engine_use_pruning", "nsh_engine_use_merge", "nsh_engine_share_scores", "nsh_engine_use_skips", "nsh_invert_segment", "nsh_invert_error",
     "nsh_engine_semantic_info", "nsh_engine_expand", "nsh_engine_semantic_row", "nsh_engine_set_cache", "nsh_engine_cache_size",
 ]
 
@@ -107,6 +108,7 @@ def hip_lib():
         L.ns_segment_build_blockmax.argtypes = [vp, vp, vp, vp, vp, u32]
         L.ns_ctx_use_pruning.argtypes = [vp, i32]
         L.ns_ctx_use_merge.argtypes = [vp, i32]
+        L.ns_ctx_share_scores.argtypes = [vp, i32]
         L.ns_sem_upload.argtypes = [vp, vp, u32, u32, C.POINTER(vp)]
         L.ns_sem_release.argtypes = [vp, vp]
         L.ns_sem_topk.argtypes = [vp, vp, vp, u32, u32, C.c_float, vp, vp, vp, vp, vp, vp]
@@ -199,6 +201,8 @@ def host_lib():
         L.nsh_engine_use_pruning.restype = None
         L.nsh_engine_use_merge.argtypes = [vp, i32]
         L.nsh_engine_use_merge.restype = None
+        L.nsh_engine_share_scores.argtypes = [vp, i32]
+        L.nsh_engine_share_scores.restype = None
         _host = L
     return _host
 
@@ -480,6 +484,10 @@ class Engine:
     def use_merge(self, on):
         """Two-list groups: the merge body (default) or the driver-stream body."""
         self._L.nsh_engine_use_merge(self.h, 1 if on else 0)
+
+    def share_scores(self, mode):
+        """0 never, 1 (default) batches that name their lists often enough, 2 every batch that can (ns_ctx_share_scores)"""
+        self._L.nsh_engine_share_scores(self.h, int(mode))
 
     def build_packed(self):
         """Build every segment's compressed, blocked posting stream on the device (optional)."""

@@ -300,6 +300,20 @@ def test_full_batches_equal_oracle_and_reference_digests(index_factory):
             if "ties" in e:
                 bad = [b for b, (x, y) in enumerate(zip(dig["ties"], e["ties"])) if x != y]
                 assert not bad, f"{cfg}: blocks {bad[:8]} differ from the real reference's tie-invariant digests"
+            # cfg3-5 name their lists often enough to share term scores by default (ns_ctx_share_scores): the digests above
+            # are that path's; scoring every posting in place must not change a byte
+            b = eng.prepare(gen(Q), K, flags)
+            inf = b.info()
+            b.close()
+            assert bool(inf.flags & nsbind.NS_INFO_SHARED) == (cfg != "cfg2"), cfg
+            assert cfg == "cfg2" or (0 < inf.shared_postings * 4 <= inf.postings and inf.shared_lists > 0)
+            eng.share_scores(0)
+            b = eng.prepare(gen(Q), K, flags)
+            assert not (b.info().flags & (nsbind.NS_INFO_SHARED | nsbind.NS_INFO_IMPACTS))
+            b.close()
+            h2, n2, f2, _ = eng.search_batch(gen(Q), K, flags)
+            assert hits.tobytes() == h2.tobytes() and nhits.tobytes() == n2.tobytes() and found.tobytes() == f2.tobytes(), (cfg, "sharing off")
+            eng.share_scores(1)
             # the skip tables reload() built (doc-tile groups on the skip grid) must not change a byte ...
             eng.use_skips(False)
             h2, n2, f2, _ = eng.search_batch(gen(Q), K, flags)
@@ -542,14 +556,22 @@ def test_overlapping_batches_and_host_thread_count(index_factory):
             assert usable.all()
             descs.append((qd, refs))
         want = [ora.search_batch(qs, 10, threads=16) for qs in sets]
-        for threads, overlap in ((1, 0), (0, 0), (5, 1), (0, 1)):
+        # share = 2: every batch computes the term scores of its distinct lists itself, into ONE buffer per segment, while the
+        # batch before it is still scoring from that buffer on the other stream (ns_ctx_share_scores)
+        for threads, overlap, share in ((1, 0, 0), (0, 0, 1), (5, 1, 0), (0, 1, 2), (3, 0, 2)):
             assert L.ns_ctx_set_host_threads(eng.ctx, threads) == 0
             assert L.ns_ctx_set_overlap(eng.ctx, overlap) == 0   # batches alternate between two streams: tails and heads overlap
+            assert L.ns_ctx_share_scores(eng.ctx, share) == 0
             got = list(nsbind.pipelined_search(eng.ctx, descs, 10, timed=True))
             assert len(got) == len(sets)
             for qs, (hits, nhits, found, inf), w in zip(sets, got, want):
                 assert inf.timed_runs == 1 and inf.n_queries == len(qs)
-                assert_same((hits, nhits, found, np.ones(len(qs), np.uint8)), w, qs, f"pipelined, host threads {threads}, overlap {overlap}")
+                if share != 1:   # (1: the default rule — the larger of these batches share, the lone query never does)
+                    assert bool(inf.flags & nsbind.NS_INFO_SHARED) == (share == 2 and inf.postings > 0) and (inf.shared_lists > 0) == (share == 2 and inf.postings > 0)
+                elif len(qs) == 1:
+                    assert not (inf.flags & nsbind.NS_INFO_SHARED)
+                assert_same((hits, nhits, found, np.ones(len(qs), np.uint8)), w, qs, f"pipelined, host threads {threads}, overlap {overlap}, share {share}")
+        assert L.ns_ctx_share_scores(eng.ctx, 1) == 0
         # the same through preallocated, reused output buffers (what bench.py does)
         k = 10
         out = [(np.empty((4400, k), dtype=nsbind.HIT_DTYPE), np.empty(4400, np.uint32), np.empty(4400, np.uint64)) for _ in range(2)]
@@ -1210,6 +1232,183 @@ def test_impact_stream_partial_registration_and_foreign_idf():
     assert L.ns_segment_build_impacts(ctx, seg, bad_off.ctypes.data, bad_cnt.ctypes.data, idfs[:2].ctypes.data, 2) != 0
     big = np.array([flat.nbytes - 8], dtype=np.uint64)
     assert L.ns_segment_build_impacts(ctx, seg, big.ctypes.data, bad_cnt[:1].ctypes.data, idfs[:1].ctypes.data, 1) != 0
+    assert L.ns_segment_release(ctx, seg) == 0
+    L.ns_ctx_destroy(ctx)
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_shared_term_scores_equal_in_place_oracle_and_reference(name, golden_index):
+    """ns_ctx_share_scores(2): the batch computes the BM25 term scores of its distinct lists once per run and scores from
+    them.  Same bytes as scoring every posting in place, as the oracle and as the real reference's captured output, in OR and
+    AND mode, at every K, under forced fine splitting and when the batch runs twice."""
+    g, d, _ = golden_index(name)
+    eng, ora = nsbind.Engine(d, 0), orc.Oracle(d)
+    try:
+        queries = g["queries"]
+        eng.share_scores(0)
+        plain = {k: eng.search_batch(queries, k) for k in (1, 10, 100)}
+        b = eng.prepare(queries, 10)
+        assert not (b.info().flags & (nsbind.NS_INFO_SHARED | nsbind.NS_INFO_IMPACTS))
+        b.close()
+        eng.share_scores(1)   # a golden batch is far too small to share by itself
+        b = eng.prepare(queries, 10)
+        assert not (b.info().flags & nsbind.NS_INFO_SHARED)
+        b.close()
+        eng.share_scores(2)
+        b = eng.prepare(queries, 10)
+        inf = b.info()
+        assert (inf.flags & nsbind.NS_INFO_SHARED) and 0 < inf.shared_lists <= inf.n_term_refs and 0 < inf.shared_postings <= inf.postings
+        first = None
+        for _ in range(2):   # a second run builds the scores again
+            b.run(False)
+            got = b.fetch()
+            first = first or got
+            for a, c in zip(got, first):
+                assert a.tobytes() == c.tobytes()
+        b.close()
+        for k in (1, 10, 100):
+            gpu = eng.search_batch(queries, k)
+            assert_same(gpu, ora.search_batch(queries, k), queries, f"{name} shared k={k}")
+            for a, c in zip(gpu, plain[k]):
+                assert a.tobytes() == c.tobytes()
+        assert_same(eng.search_batch(queries, 10, nsbind.NS_FLAG_AND), ora.search_batch(queries, 10, nsbind.NS_FLAG_AND), queries, f"{name} shared AND")
+        for case in g["cases"]:
+            gh, gn, gf, gu = eng.search_batch(queries, case["k"])
+            for qi, ref in enumerate(case["results"]):
+                if ref["found"] < 0:
+                    continue
+                assert int(gf[qi]) == ref["found"]
+                assert [int(x) for x in gh[qi, : gn[qi]]["score"].view(np.uint32)] == [h[2] for h in ref["hits"]]
+        eng.set_tuning(0, 4096, 300)
+        assert_same(eng.search_batch(queries[:20], 10), ora.search_batch(queries[:20], 10), queries[:20], f"{name} shared split")
+        eng.set_tuning(0, 0, 0)
+    finally:
+        eng.close()
+        ora.close()
+
+
+def test_shared_term_scores_refusals_and_live_batches():
+    """Raw C-ABI: when a batch may NOT share (ns_ctx_share_scores) — the same list under two idfs, a list overlapping another
+    one, an idf a live sharing batch does not use, a segment whose optional impact stream lacks a list — it scores in place;
+    either way the numpy restatement must be met, also by a live batch that runs again after others built into the buffer."""
+    L = nsbind.hip_lib()
+    ctx = C.c_void_p()
+    assert L.ns_ctx_create(0, C.byref(ctx)) == 0
+    assert L.ns_ctx_share_scores(ctx, 3) != 0 and L.ns_ctx_share_scores(ctx, 2) == 0
+    N = 150_000
+    rng = np.random.default_rng(33)
+    doc_len = rng.integers(20, 3000, size=N, dtype=np.uint32)
+    avgdl = float(np.float32(doc_len.astype(np.float64).mean()))
+    sizes = [50_000, 8_000, 400, 90_000, 23]
+    lists, payload = [], []
+    for n in sizes:
+        docs = np.sort(rng.choice(N, size=n, replace=False)).astype(np.uint32)
+        tfs = rng.integers(1, 30, size=n, dtype=np.uint32)
+        lists.append((docs, tfs))
+        payload.append(np.stack([docs, tfs], axis=1).astype(np.uint32).ravel())
+    flat = np.concatenate(payload)
+    offs = [int(x) for x in np.cumsum([0] + [len(p) * 4 for p in payload])[:-1]]
+    # list 5: the second half of list 3 named as a list of its own (it overlaps list 3); list 6: list 0's start, shorter count
+    lists.append((lists[3][0][45_000:], lists[3][1][45_000:])); offs.append(offs[3] + 45_000 * 8); sizes.append(45_000)
+    lists.append((lists[0][0][:20_000], lists[0][1][:20_000])); offs.append(offs[0]); sizes.append(20_000)
+    seg = C.c_void_p()
+    assert L.ns_segment_upload(ctx, 0, N, C.c_float(avgdl), doc_len.ctypes.data, flat.ctypes.data, flat.nbytes, C.byref(seg)) == 0, L.ns_last_error(ctx)
+    idfs = [1.5, 3.25, 6.0, 0.75, 9.5, 0.75, 1.5]
+    weights = [1.0, 0.5, 1.0, 1.0, 0.25, 1.0, 1.0]
+
+    def descs(queries, idf_of):
+        qd = np.zeros(len(queries), dtype=nsbind.QDESC_DTYPE)
+        refs = []
+        for qi, q in enumerate(queries):
+            qd[qi] = (len(refs), len(q))
+            for li in q:
+                li, idf = li if isinstance(li, tuple) else (li, idf_of[li])
+                refs.append((0, sizes[li], offs[li], idf, weights[li]))
+        return qd, np.array(refs, dtype=nsbind.TERM_DTYPE)
+
+    def check(queries, idf_of, hits, nhits, found, k, label):
+        for qi, q in enumerate(queries):
+            ids = [li[0] if isinstance(li, tuple) else li for li in q]
+            fs = [li[1] if isinstance(li, tuple) else idf_of[li] for li in q]
+            acc = _np_bm25(lists, ids, fs, [weights[i] for i in ids], doc_len, avgdl)
+            order = sorted(acc.items(), key=lambda kv: (-float(kv[1]), kv[0]))[:k]
+            n = int(nhits[qi])
+            assert int(found[qi]) == len(acc) and n == len(order), (label, qi)
+            assert [int(x) for x in hits[qi, :n]["doc"]] == [x for x, _ in order], (label, qi)
+            np.testing.assert_array_equal(hits[qi, :n]["score"].view(np.uint32), np.array([v for _, v in order], dtype=np.float32).view(np.uint32))
+
+    def prepare(queries, idf_of, expect_shared, k=10):
+        qd, refs = descs(queries, idf_of)
+        bh = C.c_void_p()
+        assert L.ns_batch_prepare(ctx, qd.ctypes.data, refs.ctypes.data, len(qd), k, 0, C.byref(bh)) == 0, L.ns_last_error(ctx)
+        info = nsbind.NsBatchInfo()
+        assert L.ns_batch_get_info(bh, C.byref(info)) == 0
+        assert bool(info.flags & nsbind.NS_INFO_SHARED) == expect_shared, (queries, info.flags)
+        return bh, (qd, refs)
+
+    def run_fetch(bh, queries, idf_of, label, k=10):
+        Q = len(queries)
+        hits = np.empty((Q, k), dtype=nsbind.HIT_DTYPE); nhits = np.zeros(Q, np.uint32); found = np.zeros(Q, np.uint64)
+        assert L.ns_batch_run(bh, 0) == 0, L.ns_last_error(ctx)
+        assert L.ns_batch_fetch(bh, hits.ctypes.data, nhits.ctypes.data, found.ctypes.data) == 0, L.ns_last_error(ctx)
+        check(queries, idf_of, hits, nhits, found, k, label)
+
+    base = [[0, 3], [3, 0, 1], [1, 2, 4], [4], [2, 0, 3, 1, 4, 0], [3], [0, 1]]
+    b1, _ = prepare(base, idfs, True)
+    run_fetch(b1, base, idfs, "shared")
+    # the same list under two idfs inside one batch: no sharing
+    two = [[0, (0, 2.0)], [3, 1]]
+    b2, _ = prepare(two, idfs, False)
+    run_fetch(b2, two, idfs, "two idfs in one batch")
+    L.ns_batch_destroy(b2)
+    # another idf for list 3 while b1 (which built it with 0.75) is alive: no sharing; b1 still right when it runs again
+    other = list(idfs); other[3] = 0.8125
+    b3, _ = prepare(base, other, False)
+    run_fetch(b3, base, other, "foreign idf, live batch")
+    run_fetch(b1, base, idfs, "live batch again")
+    # a second live sharing batch with the same idfs builds into the same buffer; both stay right in any order
+    more = [[1, 0], [2, 3, 4], [0]]
+    b4, _ = prepare(more, idfs, True)
+    run_fetch(b4, more, idfs, "second live batch")
+    run_fetch(b1, base, idfs, "first live batch after the second")
+    # the optional stream cannot be built under live sharing batches
+    o = np.array([offs[0]], np.uint64); c = np.array([sizes[0]], np.uint32); f = np.array([idfs[0]], np.float32)
+    assert L.ns_segment_build_impacts(ctx, seg, o.ctypes.data, c.ctypes.data, f.ctypes.data, 1) != 0
+    L.ns_batch_destroy(b3); L.ns_batch_destroy(b4); L.ns_batch_destroy(b1)
+    # no live sharing batch left: the new idf takes the list over
+    b5, _ = prepare(base, other, True)
+    run_fetch(b5, base, other, "idf replaced")
+    L.ns_batch_destroy(b5)
+    b6, _ = prepare(base, idfs, True)
+    run_fetch(b6, base, idfs, "idf back")
+    L.ns_batch_destroy(b6)
+    # lists that overlap a shared one (a tail of list 3, a shorter list 0) are refused, whichever batch names them
+    for q in ([[5, 1], [3]], [[6], [1, 2]], [[5]]):
+        bo, _ = prepare(q, idfs, False)
+        run_fetch(bo, q, idfs, "overlapping list")
+        L.ns_batch_destroy(bo)
+    b7, _ = prepare(base, idfs, True)   # the refusals left the registry intact
+    run_fetch(b7, base, idfs, "after refusals")
+    L.ns_batch_destroy(b7)
+    # K = 100 and the one-shot entry point
+    qd, refs = descs(base, idfs)
+    rc, hits, nhits, found = nsbind.search_batch_raw(ctx, qd, refs, 100)
+    assert rc == 0
+    check(base, idfs, hits, nhits, found, 100, "one-shot K=100")
+    # a segment with an optional impact stream that lacks one of the batch's lists: in place; with all of them: that stream
+    o = np.array(offs[:4], np.uint64); c = np.array(sizes[:4], np.uint32); f = np.array(idfs[:4], np.float32)
+    assert L.ns_segment_build_impacts(ctx, seg, o.ctypes.data, c.ctypes.data, f.ctypes.data, 4) == 0, L.ns_last_error(ctx)
+    b8, _ = prepare(base, idfs, False)
+    info = nsbind.NsBatchInfo(); L.ns_batch_get_info(b8, C.byref(info))
+    assert not (info.flags & nsbind.NS_INFO_IMPACTS)
+    run_fetch(b8, base, idfs, "optional stream lacks a list")
+    L.ns_batch_destroy(b8)
+    part = [[0, 3], [3, 0, 1], [1]]
+    b9, _ = prepare(part, idfs, False)
+    info = nsbind.NsBatchInfo(); L.ns_batch_get_info(b9, C.byref(info))
+    assert info.flags & nsbind.NS_INFO_IMPACTS
+    run_fetch(b9, part, idfs, "optional stream")
+    L.ns_batch_destroy(b9)
     assert L.ns_segment_release(ctx, seg) == 0
     L.ns_ctx_destroy(ctx)
 

@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--packed", type=int, default=0, help="build the packed posting streams first and read them in this mode (1: norms from the fp32 stream, 2: through the 16-bit norm index)")
     ap.add_argument("--prune", action="store_true", help="build block maxima and let single-term queries skip blocks (ns_ctx_use_pruning)")
     ap.add_argument("--no-skips", action="store_true", help="ignore the skip tables reload() built")
+    ap.add_argument("--share", type=int, default=-1, help="ns_ctx_share_scores mode (0 never, 1 default rule, 2 always); -1: leave the library's default")
     ap.add_argument("--segments", type=int, default=1, help="segments of --docs docs each (20 x 1M docs = 1.1 GB of postings: beyond the 256 MiB Infinity Cache)")
     ap.add_argument("--docs", type=int, default=1_000_000)
     ap.add_argument("--qscale", type=float, default=1.0, help="keep only this fraction of every law's queries (every query scans every segment)")
@@ -110,6 +111,8 @@ def main():
         eng.use_packed(args.packed)
     if args.no_skips:
         eng.use_skips(False)
+    if args.share >= 0:
+        eng.share_scores(args.share)
     if args.prune:
         eng.build_blockmax()
         eng.use_pruning(True)
@@ -119,7 +122,7 @@ def main():
         L = {n: (qs[:max(1, int(len(qs) * args.qscale))], k) for n, (qs, k) in L.items()}
     L["scan_once"] = ([T(r) for r in range(1, 4097)], 10)
     names = [n for n in args.laws.split(",") if n] or list(L.keys())
-    print(f"variant={args.variant} split={args.split} prune={args.prune} impacts={args.impacts} packed={args.packed} segments={args.segments} docs={args.docs} qscale={args.qscale}")
+    print(f"variant={args.variant} split={args.split} share={args.share} prune={args.prune} impacts={args.impacts} packed={args.packed} segments={args.segments} docs={args.docs} qscale={args.qscale}")
     print(f"{'law':>14} {'Q':>6} {'post/q':>9} {'items':>7} {'kern_ms':>9} {'ns/post':>8} {'GB/s':>8} {'frac':>6} {'all_ms':>8}")
     for n in names:
         qs, k = L[n]
@@ -135,7 +138,8 @@ def main():
         inf = b.info()
         ms = inf.sum_score_kernel_ms / inf.timed_runs
         gbs = inf.algo_bytes / (ms * 1e-3) / 1e9
-        print(f"{n:>14} {len(qs):>6} {inf.postings / len(qs):>9.0f} {inf.n_items:>7} {ms:>9.3f} {ms * 1e6 / inf.postings:>8.4f} {gbs:>8.0f} {gbs / 8000:>6.3f} {inf.sum_total_ms / inf.timed_runs:>8.3f}")
+        print(f"{n:>14} {len(qs):>6} {inf.postings / len(qs):>9.0f} {inf.n_items:>7} {ms:>9.3f} {ms * 1e6 / inf.postings:>8.4f} {gbs:>8.0f} {gbs / 8000:>6.3f} {inf.sum_total_ms / inf.timed_runs:>8.3f}"
+              + (f"   shared: {inf.shared_lists} lists, {inf.shared_postings} postings" if inf.shared_lists else ""))
         b.close()
     eng.close()
 
