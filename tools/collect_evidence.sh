@@ -55,6 +55,9 @@ if [[ $PART == *B* ]]; then
     echo "#### $sw" >> $O/law_bench.txt
     env $sw timeout -k 10 300 python3 tools/law_bench.py --laws cfg5,cfg5_thin,cfg5_tile,cfg5_gen,cfg5_t2_gen,r8r20,r40r60,r8r300,cfg3,cfg5_q2048 >> $O/law_bench.txt 2>&1 || exit 1
   done
+  # every posting scored in place (ns_ctx_share_scores(0)): the laws that share term scores by default
+  echo "#### NS_SHARE=0" >> $O/law_bench.txt
+  NS_SHARE=0 timeout -k 10 300 python3 tools/law_bench.py --laws r1,r8,cfg5,cfg5_seed7,cfg5_top1,cfg5_thin,cfg5_tile,cfg5_gen,cfg5_2hot_gen,cfg5_t2_gen,cfg3,cfg3_k10,cfg5_q4096,cfg5_seed99_q32768,hot5_k10 >> $O/law_bench.txt 2>&1 || exit 1
   BIG="--segments 20 --qscale 0.125"
   BL=cfg5,cfg5_thin,cfg5_tile,cfg5_gen,scan_once,r1,r8,r100,r1000,cfg3_k10,cfg5_top1
   for opt in "" "--packed 1" "--prune" "--impacts"; do

@@ -32,6 +32,12 @@ for a, b in (("law_bench.txt", "final_law_bench.txt"), ("law_big20.txt", "final_
 if os.path.exists(f"{O}/pmc_fetch/cfg5_counter_collection.csv"):
     f = counters(f"{O}/pmc_fetch/cfg5_counter_collection.csv", "FETCH_SIZE"); w = counters(f"{O}/pmc_write/cfg5_counter_collection.csv", "WRITE_SIZE")
     fm = sum(x[2] for x in f) / len(f); wm = sum(x[2] for x in w) / len(w)
+    # a sharing batch (ns_ctx_share_scores) runs k_share_scores in front of every scoring launch: one step = both kernels
+    fs = counters(f"{O}/pmc_fetch/cfg5_counter_collection.csv", "FETCH_SIZE", "k_share_scores"); ws = counters(f"{O}/pmc_write/cfg5_counter_collection.csv", "WRITE_SIZE", "k_share_scores")
+    if fs:
+        print("k_share_scores per launch: FETCH_SIZE", sum(x[2] for x in fs) / len(fs), "KB, WRITE_SIZE", sum(x[2] for x in ws) / max(len(ws), 1), "KB")
+        fm += sum(x[2] for x in fs) / len(fs); wm += sum(x[2] for x in ws) / max(len(ws), 1)
+        f += fs; w += ws
     traffic = (2 * fm + wm) * 1024
     print("cfg5 L2-miss traffic per launch (2 x FETCH + WRITE):", traffic)
     with open(f"{P}/final_cfg5_pmc_traffic.csv", "w") as out:

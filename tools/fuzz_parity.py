@@ -98,10 +98,12 @@ def _run(rng, t0, last, cases, tmp, seconds, max_cases, verbose):
                 if prune:
                     eng.build_blockmax()
                 eng.use_pruning(prune)
+                share = rng.choice([0, 2, 2])   # term scores computed once per distinct list of the batch (until the engine has an optional impact stream)
+                eng.share_scores(share)
                 bad = same(eng.search_batch(qs, k, flags), ora.search_batch(qs, k, flags, threads=8))
                 if bad:
                     return cases, (f"MISMATCH {bad}: index(nseg={nseg}, docs={docs}, vocab={vocab}, seed={seed}) law={law} nq={nq} k={k} "
-                                   f"flags={flags} tune={tune} impacts={imp} packed={pk} skips={skips} merge={merge} prune={prune} queries={qs[:5]}")
+                                   f"flags={flags} tune={tune} impacts={imp} packed={pk} skips={skips} merge={merge} prune={prune} share={share} queries={qs[:5]}")
                 cases += 1
                 if verbose and time.time() - last > 30:
                     last = time.time()
