@@ -676,7 +676,7 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
                 // the term order (foreign terms before it are already in, those after it follow)
 #pragma unroll
                 for (int j = 0; j < DE; j++) {
-                    if (PK ? (dokm[j] == 0ull) : ((uint32_t)(j * 64) >= n)) continue;   // uniform: no posting of this round in the chunk
+                    if (dokm[j] == 0ull) continue;   // uniform: the super-batch takes no posting of this chunk (docIds ascend: the round that reaches `hi` usually leaves its last chunks untaken)
                     const uint32_t tag = NS_TAG(ps[j].x);
                     const uint32_t hb = NS_BUCKET(ps[j].x);   // in range whatever the docId; only postings of this super-batch count (dokm)
                     uint32_t b = hb;
