@@ -161,7 +161,8 @@ int ns_segment_build_packed(ns_ctx* ctx, ns_seg* seg);
  * memory latency per round).  mode 2: the norms come through the blocks' 16-bit norm index instead (4-5 B per posting, but
  * the table look-up is a second, dependent access per round). */
 int ns_ctx_use_packed(ns_ctx* ctx, int mode);
-/* on = 0: batches prepared from now on ignore impact streams (default: on = 1). */
+/* on = 0: batches prepared from now on ignore impact streams, and do not share term scores either (ns_ctx_share_scores builds
+ * into the same per-segment buffer) (default: on = 1). */
 int ns_ctx_use_impacts(ns_ctx* ctx, int on);
 /* Skip tables (block metadata next to the reference's raw posting format, src/lexicon.cpp:104-128,
  * which has none: the reference walks every list from its first posting, src/api_engine.cpp:470-481).  For every list

@@ -591,6 +591,21 @@ extern "C" int ns_segment_release(ns_ctx* ctx, ns_seg* seg) {
     if (ctx->pull_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->pull_stream));
     seg_free_staging(seg);
     seg_free_device(seg);
+    // the shared-score registry forgets the segment's lists: a later segment under the same id starts with an empty interval map
+    // and must see every one of its lists as new (that is when overlaps are checked)
+    if (!seg->pending && ctx->share_n) {
+        std::vector<ns_ctx::ShareEnt> kept(ctx->share_tab.size());
+        const size_t m = kept.size() - 1;
+        size_t n = 0;
+        for (const auto& en : ctx->share_tab)
+            if (en.key != ~0ull && (uint32_t)(en.key >> 32) != seg->id) {
+                size_t h = (size_t)((en.key * 0x9E3779B97F4A7C15ull) >> 20) & m;
+                while (kept[h].key != ~0ull) h = (h + 1) & m;
+                kept[h] = en; n++;
+            }
+        ctx->share_tab.swap(kept);
+        ctx->share_n = n;
+    }
     if (!seg->pending) ctx->segs[seg->id] = nullptr;
     else ctx->pending_uploads.erase(std::remove(ctx->pending_uploads.begin(), ctx->pending_uploads.end(), seg), ctx->pending_uploads.end());
     delete seg;

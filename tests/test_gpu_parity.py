@@ -1410,6 +1410,21 @@ def test_shared_term_scores_refusals_and_live_batches():
     run_fetch(b9, part, idfs, "optional stream")
     L.ns_batch_destroy(b9)
     assert L.ns_segment_release(ctx, seg) == 0
+    # a NEW segment under the released segment's id: the registry has forgotten the old lists (list 7 starts where list 0 did, with
+    # another count: it is a new list, admitted and shared), and overlaps are checked afresh (list 8 overlaps list 7: refused)
+    lists.append((lists[0][0][:30_000], lists[0][1][:30_000])); offs.append(offs[0]); sizes.append(30_000); idfs.append(2.5); weights.append(1.0)
+    lists.append((lists[0][0][10_000:40_000], lists[0][1][10_000:40_000])); offs.append(offs[0] + 10_000 * 8); sizes.append(30_000); idfs.append(2.5); weights.append(1.0)
+    seg2 = C.c_void_p()
+    assert L.ns_segment_upload(ctx, 0, N, C.c_float(avgdl), doc_len.ctypes.data, flat.ctypes.data, flat.nbytes, C.byref(seg2)) == 0, L.ns_last_error(ctx)
+    fresh = [[7, 1], [7], [2, 7, 4]]
+    b10, _ = prepare(fresh, idfs, True)
+    run_fetch(b10, fresh, idfs, "new segment under the old id")
+    L.ns_batch_destroy(b10)
+    over = [[8, 1], [7]]
+    b11, _ = prepare(over, idfs, False)
+    run_fetch(b11, over, idfs, "overlap in the new segment")
+    L.ns_batch_destroy(b11)
+    assert L.ns_segment_release(ctx, seg2) == 0
     L.ns_ctx_destroy(ctx)
 
 
