@@ -307,6 +307,7 @@ class Engine:
 
     def close(self):
         if self.h:
+            close_batches_of(self.ctx)   # a batch must not outlive its device context
             self._L.nsh_engine_close(self.h)
             self.h = None
 
@@ -322,8 +323,11 @@ class Engine:
 
     def reload(self):
         """Engine::reload() on the same directory; on failure the engine keeps what it had."""
+        old_ctx = self.ctx
         if self._L.nsh_engine_reload(self.h) != 0:
             raise RuntimeError(f"Engine.reload failed: {self.error()}")
+        if _ctx_key(self.ctx) != _ctx_key(old_ctx):
+            _LIVE_BATCHES.pop(_ctx_key(old_ctx), None)   # (the header: fetch and destroy an engine's batches before reloading it)
 
     def error(self):
         return self._L.nsh_engine_error(self.h).decode()
@@ -437,7 +441,10 @@ class Engine:
         rc = self._L.nsh_engine_prepare(self.h, _cstr_array(queries), len(queries), k, flags, C.byref(b))
         if rc != 0:
             raise RuntimeError(f"prepare failed: {self.error()}")
-        return Batch(b, len(queries), clamp_k(k))
+        import weakref
+        bt = Batch(b, len(queries), clamp_k(k))
+        _LIVE_BATCHES.setdefault(_ctx_key(self.ctx), weakref.WeakSet()).add(bt)
+        return bt
 
     def set_cache(self, on):
         self._L.nsh_engine_set_cache(self.h, 1 if on else 0)
@@ -524,13 +531,31 @@ def u64_():
     return C.c_uint64()
 
 
+# Batches alive per device context (keyed by the ctx pointer): a batch must be destroyed BEFORE its ctx (it returns its
+# blocks and pinned slots to it).  A test that fails between prepare() and close() keeps its Batch alive in the traceback
+# while its `finally` closes the engine; the engine therefore closes what is left of its batches first (close_batches_of).
+_LIVE_BATCHES = {}
+
+
+def _ctx_key(ctx):
+    return ctx.value if isinstance(ctx, C.c_void_p) else int(ctx) if ctx else 0
+
+
+def close_batches_of(ctx):
+    for b in list(_LIVE_BATCHES.pop(_ctx_key(ctx), ())):
+        b.close()
+
+
 def prepare_raw(ctx, qd, refs, k, flags=NS_FLAG_OR):
     """ns_batch_prepare on descriptor arrays that are already in the C-ABI's layout (numpy QDESC_DTYPE / TERM_DTYPE)."""
+    import weakref
     b = C.c_void_p()
     rc = hip_lib().ns_batch_prepare(ctx, qd.ctypes.data, refs.ctypes.data if len(refs) else None, len(qd), int(k), flags, C.byref(b))
     if rc != NS_OK:
         raise RuntimeError("ns_batch_prepare: " + hip_lib().ns_last_error(ctx).decode())
-    return Batch(b, len(qd), int(k))
+    bt = Batch(b, len(qd), int(k))
+    _LIVE_BATCHES.setdefault(_ctx_key(ctx), weakref.WeakSet()).add(bt)
+    return bt
 
 
 def pipelined_search(ctx, batches, k, flags=NS_FLAG_OR, out=None, timed=False, depth=2):

@@ -140,6 +140,26 @@ def test_forced_kernel_variants_in_the_variants_build():
     assert " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], tail
 
 
+def test_every_parity_case_again_with_term_scores_shared():
+    """NS_SHARE=2 in the environment makes every batch that can compute its lists' term scores once and score from them
+    (ns_ctx_share_scores(2) for every ctx created): the parity cases of this file — goldens, splitting, zero-tf and signed
+    inputs, equal scores, the fuzz slice, > 64 terms, sparse lists over 20 M docs, damaged lexicons, raw-ABI weights, the
+    short-division range — must hold unchanged on that path.  ONE child process; the cases that assert which path a batch took
+    (they set the mode themselves) and the child-process cases stay out."""
+    import subprocess
+    import sys
+    if os.environ.get("NS_SHARE") is not None:
+        pytest.skip("this IS the forced-sharing process")
+    env = dict(os.environ, NS_SHARE="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider", "-k",
+                        "not full_batches_equal and not impact_stream and not shared_term_scores and not forced_kernel_variants "
+                        "and not every_parity_case_again and not overlapping_batches"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert " passed" in r.stdout, tail
+
+
 @pytest.mark.parametrize("variant,split", [(0, 0), (0, 300), (12, 0), (13, 200), (18, 0), (19, 0), (20, 300), (2, 0)])
 def test_zero_tf_postings_and_signed_weights(variant, split):
     """`found` (src/api_engine.cpp:495) counts a doc once some term touches it, whatever the contribution: a posting
