@@ -535,9 +535,11 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
             if (tt == dl) continue;                                                                \
             NS_CNT(7, 1);                                                                          \
             float old_[FE];                                                                        \
+            /* every lane reads (lanes of other terms their own posting's slot, a valid address whose value they drop): */ \
+            /* no exec juggling around the reads, only around the writes */                        \
             _Pragma("unroll") for (int j = 0; j < FE; j++) {                                       \
-                old_[j] = 0.0f;                                                                    \
-                if (fok[j] && (ftj[j] & 63u) == tt) old_[j] = vals[(ftj[j] >> 6) & 255u];          \
+                const bool c_ = fok[j] && (ftj[j] & 63u) == tt;                                    \
+                old_[j] = vals[c_ ? ((ftj[j] >> 6) & 255u) : (uint32_t)(j * 64 + lane)];           \
             }                                                                                      \
             _Pragma("unroll") for (int j = 0; j < FE; j++) {                                       \
                 if (fok[j] && (ftj[j] & 63u) == tt) {                                              \
@@ -736,18 +738,17 @@ __device__ __forceinline__ void dscore_body(const DevWItem& it, const DevTerm* _
             bool scored[FE];
 #pragma unroll
             for (int j = 0; j < FE; j++) {
-                fin[j] = 0.0f;
+                // (every lane reads and clears its own posting's slot — a non-owner's is unused and stays +0.0f: no exec
+                // juggling around the accumulators, only around the table entries, which only their owners may touch)
+                fin[j] = vals[j * 64 + lane];
                 scored[j] = fmine[j];
-                if (fmine[j]) {
-                    fin[j] = vals[j * 64 + lane];
-                    if (AND) scored[j] = (mcnt[j * 64 + lane] == (uint8_t)T);   // conjunctive extension: every term ref hit the doc
-                }
+                if (AND && fmine[j]) scored[j] = (mcnt[j * 64 + lane] == (uint8_t)T);   // conjunctive extension: every term ref hit the doc
             }
             wave_sync();
 #pragma unroll
             for (int j = 0; j < FE; j++) {
-                if (fmine[j]) {   // the owner resets its entry and accumulator for the next super-batch
-                    vals[j * 64 + lane] = 0.0f;
+                vals[j * 64 + lane] = 0.0f;
+                if (fmine[j]) {   // the owner resets its entry for the next super-batch
                     ent[ftj[j] >> 14] = EMPTY;
                     if (AND) mcnt[j * 64 + lane] = 0;
                 }
