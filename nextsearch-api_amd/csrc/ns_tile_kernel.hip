@@ -263,7 +263,7 @@ __device__ __forceinline__ void tscore_body(const DevWItem& it, const DevTerm* _
                         const int j = (J0) + jj;                                                   \
                         slot[j] = (ps[j].x - tile_lo) & (uint32_t)(TD - 1);                        \
                         if (takem[j] == 0ull) continue;   /* uniform */                            \
-                        if (__builtin_amdgcn_inverse_ballot_w64(takem[j])) old[j] = vals[slot[j]]; \
+                        old[j] = vals[slot[j]];   /* every lane reads (the slot index is masked, the value of a lane that does not take is dropped) */ \
                         /* `found` (:495) counts a doc when its slot is touched for the first time (OR mode; the */ \
                         /* conjunctive extension counts in the read-back, where the per-doc term counts are known); */ \
                         /* a first touch starts from the reference's +0.0f (:480), whatever the contribution is */ \
