@@ -24,7 +24,9 @@
 
 namespace ns {
 
-template <bool AND, int CB>
+// IMP: both lists have their term scores in the segment's score stream ({docId, score bits}, index-aligned with the postings:
+// the optional impact stream, or the batch's shared term scores): no tf, no norm, no division here (see dscore_body).
+template <bool AND, int CB, bool IMP = false>
 __device__ __forceinline__ void mscore_body(const DevWItem& it, const DevTerm* __restrict__ terms, const DevSeg* __restrict__ segs,
                                             uint32_t* l_docs /* 256 */, float* l_sc /* 256 */, uint64_t* cand,
                                             Hit* __restrict__ out_hits, uint32_t* __restrict__ out_nhits,
@@ -34,7 +36,7 @@ __device__ __forceinline__ void mscore_body(const DevWItem& it, const DevTerm* _
     constexpr uint32_t kNone = 0xFFFFFFFFu, kMark = 0xFFFFFFFEu;
     const DevSeg seg = segs[it.seg];
     const bool fast_div = (__builtin_amdgcn_readfirstlane((int)it.whole) & 8) != 0;
-    const gp_u2 postings = (gp_u2)seg.postings;
+    const gp_u2 postings = IMP ? (gp_u2)seg.impacts : (gp_u2)seg.postings;
     const gp_f32 pnorm = (gp_f32)seg.pnorm;
 
     // ---- lanes 0 and 1 own the two terms: absolute posting range of the item in each list ----
@@ -113,7 +115,7 @@ __device__ __forceinline__ void mscore_body(const DevWItem& it, const DevTerm* _
             for (int j = 0; j < DE; j++) {
                 if ((uint32_t)(j * 64) >= na) { pa[j] = nat_u2{kNone, 0u}; na_[j] = 1.0f; continue; }   // uniform
                 pa[j] = sa[j * 64 + lane];
-                na_[j] = fa[j * 64 + lane];
+                na_[j] = IMP ? 1.0f : fa[j * 64 + lane];
             }
             const gp_u2 sb = postings + b_cur;
             const gp_f32 fb = pnorm + b_cur;
@@ -121,7 +123,7 @@ __device__ __forceinline__ void mscore_body(const DevWItem& it, const DevTerm* _
             for (int j = 0; j < BE; j++) {
                 if ((uint32_t)(j * 64) >= nb) { pb[j] = nat_u2{kNone, 0u}; nb_[j] = 1.0f; continue; }   // uniform
                 pb[j] = sb[j * 64 + lane];
-                nb_[j] = fb[j * 64 + lane];
+                nb_[j] = IMP ? 1.0f : fb[j * 64 + lane];
             }
         }
         // ---- hi: every posting <= hi of both lists is loaded ----
@@ -160,6 +162,12 @@ __device__ __forceinline__ void mscore_body(const DevWItem& it, const DevTerm* _
         }
         // ---- BM25 term scores (src/api_engine.cpp:477-480) ----
         float xa[DE], xb[BE];
+        if (IMP) {
+#pragma unroll
+            for (int j = 0; j < DE; j++) xa[j] = a_wq * __uint_as_float(pa[j].y);
+#pragma unroll
+            for (int j = 0; j < BE; j++) xb[j] = b_wq * __uint_as_float(pb[j].y);
+        } else {
         {
             float num[DE], den[DE];
 #pragma unroll
@@ -183,6 +191,7 @@ __device__ __forceinline__ void mscore_body(const DevWItem& it, const DevTerm* _
             ns_div_n<BE>(xb, num, den, fast_div);
 #pragma unroll
             for (int j = 0; j < BE; j++) xb[j] = b_wq * xb[j];
+        }
         }
         // ---- A's taken postings to LDS in posting order (ascending docIds; everything else ~0) ----
 #pragma unroll
@@ -212,7 +221,7 @@ __device__ __forceinline__ void mscore_body(const DevWItem& it, const DevTerm* _
         for (int j = 0; j < BE; j++) {
             xam[j] = 0.0f;
             if (mb[j] == 0ull) continue;   // uniform
-            if (__builtin_amdgcn_inverse_ballot_w64(mb[j])) xam[j] = l_sc[posb[j]];
+            xam[j] = l_sc[posb[j]];   // (every lane reads: posb is a valid slot for all of them; only matched lanes use the value)
         }
         wave_sync();
 #pragma unroll

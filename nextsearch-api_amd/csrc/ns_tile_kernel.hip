@@ -462,7 +462,7 @@ __global__ void __launch_bounds__(64 * kUscoreWavesPerBlock) __attribute__((amdg
     if (pruned)
         pscore_body<AND, CB>(it, terms, segs, s_cand[wave], out_hits, out_nhits, out_found, K, lane);
     else if (merge2)
-        mscore_body<AND, CB>(it, terms, segs, s_tbl[wave], reinterpret_cast<float*>(s_tbl[wave] + 256), s_cand[wave],
+        mscore_body<AND, CB, IMP>(it, terms, segs, s_tbl[wave], reinterpret_cast<float*>(s_tbl[wave] + 256), s_cand[wave],
                              out_hits, out_nhits, out_found, K, lane);
     else if (thin)
         dscore_body<HK / 2, 64, AND, CB, IMP, PK>(it, terms, segs, s_tbl[wave], s_vals[wave], s_mcnt[wave], s_cand[wave],
