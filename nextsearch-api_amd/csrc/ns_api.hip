@@ -183,6 +183,7 @@ struct ns_ctx {
     int use_packed = 1;        // 0 off; 1, 2: batches read the packed stream when every segment they touch has one (ns_ctx_use_packed)
     bool use_skips = true;     // doc-tile groups walk the skip grid when their lists have skip tables (ns_ctx_use_skips)
     bool use_merge = true;     // general-class groups of exactly two term refs take the two-list merge body (ns_ctx_use_merge)
+    uint32_t merge_ratio = 8;  // ... when the longer list is at most this many times the shorter (NS_MERGE_RATIO: sweeps)
     bool use_pruning = false;  // single-term groups whose list has block maxima skip the blocks that cannot enter the top-K (ns_ctx_use_pruning)
     ns_prep* prep = nullptr;   // ns_batch_prepare's host threads and per-thread scratch, kept from batch to batch
     unsigned prep_threads = 0; // 0 = automatic (up to 8); 1 = prepare on the calling thread only (ns_ctx_set_host_threads)
@@ -313,6 +314,7 @@ extern "C" int ns_ctx_create(int device, ns_ctx** out) {
     }
     if (const char* td = std::getenv("NS_TILE_DENS64")) ctx->tile_dens64 = (uint32_t)std::max(1, std::atoi(td));
     if (const char* um = std::getenv("NS_MERGE")) ctx->use_merge = std::atoi(um) != 0;
+    if (const char* mr = std::getenv("NS_MERGE_RATIO")) ctx->merge_ratio = (uint32_t)std::max(1, std::atoi(mr));
     if (const char* sm = std::getenv("NS_SHARE")) ctx->share_mode = std::max(0, std::min(2, std::atoi(sm)));
     if (const char* sr = std::getenv("NS_SHARE_RATIO")) ctx->share_ratio = (uint32_t)std::max(1, std::atoi(sr));
     if (const char* sp = std::getenv("NS_SHARE_MIN")) ctx->share_min_postings = (uint64_t)std::max(0ll, std::atoll(sp));
@@ -1399,7 +1401,7 @@ extern "C" int ns_batch_prepare(ns_ctx* ctx, const ns_query_desc* queries, const
                     // two lists, general class: the merge body (no table): both lists cost about alike per posting
                     // (two COMPARABLE lists: when one is more than 8x the other, a window of the short one per round of the long
                     // one is mostly padding and the table path is as good: r8 + r300, 37 : 1, measured 3 % slower with the merge)
-                    hg.merge2 = auto_mode && ctx->use_merge && hg.cls == 0 && hg.g.term_count == 2 && rest * 8 >= hg.cmax;
+                    hg.merge2 = auto_mode && ctx->use_merge && hg.cls == 0 && hg.g.term_count == 2 && rest * ctx->merge_ratio >= hg.cmax;
                     if (hg.merge2) hg.work = hg.cmax + rest * kWorkMerge;
                 }
                 if (!hg.wave) {
