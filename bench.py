@@ -574,8 +574,8 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": "L2-miss bytes per launch from the builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --kernel-only` (x2 gfx950 FETCH_SIZE correction), profiles/r03/final_cfg5_pmc_traffic.csv; not measured in this run",
-                "limited_by": ("instruction issue: this index (83 MB on the device) is cache resident — with the XCD-aware launch order and the shared term scores a step misses L2 for 0.2x its algorithmic bytes — "
-                               "and the SIMDs' vector and scalar issue slots are 75 % / 77 % busy (profiles/r03/final_cfg5_pmc_sq.csv: SQ_ACTIVE_INST_VALU / SQ_INSTS_SALU vs SQ_BUSY_CYCLES; 83 % / 73 % when every posting is scored in place); see hbm_resident for the HBM-resident leg")
+                "limited_by": ("instruction issue: this index (83 MB on the device) is cache resident — with the XCD-aware launch order and the shared term scores a step misses L2 for 0.15x its algorithmic bytes — "
+                               "and the SIMDs' vector and scalar issue slots are 76 % / 76 % busy (profiles/r03/final_cfg5_pmc_sq.csv: SQ_ACTIVE_INST_VALU / SQ_INSTS_SALU vs SQ_BUSY_CYCLES; 83 % / 73 % when every posting is scored in place); see hbm_resident for the HBM-resident leg")
                               if args.config in ("cfg5", "cfg3", "cfg4") else "launch latency (a few tens of microseconds of work)",
                 "algo_bytes_per_launch": int(kinfo.algo_bytes),
                 "kernel_ms": score_ms,
